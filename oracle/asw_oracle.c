@@ -1,0 +1,990 @@
+/*
+ * asw_oracle.c -- CPU restatement of the aswStereoMatch hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the MI355X implementation in aswstereomatch_amd/.  It is
+ * imported / linked only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * The product path never calls it.
+ *
+ * PARITY UNPINNED: the reference (ZhangYY12345/aswStereoMatch) ships no tests, fixtures or
+ * golden images, and its arithmetic primitives live in OpenCV 4.1.0, which is neither vendored
+ * in /root/reference nor installed here, so the reference cannot be compiled.  Every OpenCV
+ * primitive is restated below from its published portable C++ algorithm;
+ * the reference's own loops are followed line by line (citations are to
+ * aswStereoMatch/methods/aswMethods.cpp, "M.cpp").  Hand-derivable known-answer tests
+ *  pin what can be pinned without OpenCV.
+ *
+ * Build: gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ * -ffp-contract=off matters: the reference is built by MSVC for x64/SSE2, which never fuses
+ * a*b+c, and several results (M.cpp:1104-1108, 1488-1492, 22-31) depend on that.
+ *
+ * Layout conventions: images are row-major, interleaved channels (cv::Mat continuous layout);
+ * cost volumes are d-major [d][y][x], index 0 <-> disparity minDisparity, like the
+ * reference's std::vector<cv::Mat>.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_SIZE_MISMATCH 1  /* reference: silent return (M.cpp:217-220, 430-433) */
+#define ORC_ERR_EVEN_WINDOW 2    /* reference: return Mat() (M.cpp:654-657, 1440-1443, 2458-2462) */
+#define ORC_ERR_UNSUPPORTED_LAYOUT 4 /* reference: cv::Exception */
+#define ORC_ERR_ALLOC 6
+
+#define DISPARITY_LEFT 0  /* parametersStereo.h:4-8 */
+#define DISPARITY_RIGHT 1
+
+static int g_threads = 1;
+
+void orc_set_threads(int n)
+{
+    g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#endif
+}
+
+int orc_get_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
+/* ---------------------------------------------------------------------------------------
+ * OpenCV primitive restatements
+ * ------------------------------------------------------------------------------------- */
+
+/* cv::borderInterpolate, BORDER_REFLECT (fedcba|abcdefgh|hgfedcb), repeated if far out. A-2 */
+static inline int reflect_idx(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0) p = -p - 1;
+        else p = len - 1 - (p - len);
+    }
+    return p;
+}
+
+/* BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba): default of boxFilter / filter2D. A-3 */
+static inline int reflect101_idx(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0) p = -p;
+        else p = len - 1 - (p - len) - 1;
+    }
+    return p;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+/* cvtColor(COLOR_BGR2GRAY) on 8U: 14-bit fixed point BT.601, OpenCV 4.1.0 (A-1).
+ * M.cpp:1031,1033,2448,2454. */
+void orc_bgr2gray(const uint8_t* bgr, int H, int W, uint8_t* gray)
+{
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899, shift = 14;
+    for (long i = 0; i < (long)H * W; i++) {
+        int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (shift - 1))) >> shift);
+    }
+}
+
+/* u8 MatExpr (c0 + c1 + c2) / 3  ==  addWeighted(saturate(c0+c1), 1/3, c2, 1/3, 0)  (A-4).
+ * OpenCV's 8u addWeighted works in float and rounds half-to-even (cvRound). */
+static inline uint8_t mean3_u8(int c0, int c1, int c2)
+{
+    int t = c0 + c1;
+    if (t > 255) t = 255;
+    const float a = (float)(1.0 / 3.0);
+    float v = (float)t * a + (float)c2 * a;
+    long r = lrintf(v); /* default rounding mode = to nearest even, like cvRound */
+    if (r > 255) r = 255;
+    if (r < 0) r = 0;
+    return (uint8_t)r;
+}
+
+static inline int absdiff_u8(int a, int b) { return a > b ? a - b : b - a; }
+
+/* ---------------------------------------------------------------------------------------
+ * Cost builders
+ * ------------------------------------------------------------------------------------- */
+
+/* computeAD, M.cpp:208-292.  C = 1 or 3 channels.  cost: numD planes of H x W u8. */
+int orc_compute_ad(const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type,
+                   int minD, int numD, uint8_t* cost)
+{
+    if (C != 1 && C != 3) return ORC_ERR_UNSUPPORTED_LAYOUT; /* reference: no branch taken */
+    const int min_off = minD; /* M.cpp:214-215 */
+    for (int k = 0; k < numD; k++) {
+        const int off = min_off + k;
+        uint8_t* out = cost + (size_t)k * H * W;
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {
+                const uint8_t *a, *b;
+                if (disp_type == DISPARITY_LEFT) {
+                    /* right_border(Rect(max_offset - offset,...)) with a REFLECT left pad of
+                     * max_offset columns: column x reads R[reflect(x - offset)].  M.cpp:232,237 */
+                    a = L + ((size_t)y * W + x) * C;
+                    b = R + ((size_t)y * W + reflect_idx(x - off, W)) * C;
+                } else {
+                    /* left_border(Rect(offset,...)) with a REFLECT right pad.  M.cpp:249,254 */
+                    a = R + ((size_t)y * W + x) * C;
+                    b = L + ((size_t)y * W + reflect_idx(x + off, W)) * C;
+                }
+                if (C == 3)
+                    out[(size_t)y * W + x] = mean3_u8(absdiff_u8(a[0], b[0]), absdiff_u8(a[1], b[1]),
+                                                      absdiff_u8(a[2], b[2])); /* M.cpp:240-241 */
+                else
+                    out[(size_t)y * W + x] = (uint8_t)absdiff_u8(a[0], b[0]); /* M.cpp:274 */
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* computeTAD, M.cpp:304-401: AD then compare(> T) -> 0/255 mask (App. B-4). */
+int orc_compute_tad(const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type,
+                    int threshold_T, int minD, int numD, uint8_t* cost)
+{
+    int rc = orc_compute_ad(L, R, H, W, C, disp_type, minD, numD, cost);
+    if (rc != ORC_OK) return rc;
+    /* cv::compare(u8, int scalar): scalar compared exactly; T<0 -> all 255, T>=255 -> all 0 */
+    for (size_t i = 0; i < (size_t)numD * H * W; i++) cost[i] = ((int)cost[i] > threshold_T) ? 255 : 0;
+    return ORC_OK;
+}
+
+/* filter2D(src 8UC3, CV_32F, Scharr-x char kernel), REFLECT_101, on an image given through an
+ * accessor so that the right image can be the REFLECT-padded one.  M.cpp:446-450 (A-7).
+ * px(y, c, ch) must be valid for y in [0,H), c in [0,Wimg). */
+typedef struct {
+    const uint8_t* img;
+    int H, W;     /* original size */
+    int pad_left; /* REFLECT pad on the left (bordered image is W + pad_left wide) */
+} padded_img_t;
+
+static inline int padded_px(const padded_img_t* p, int y, int c, int ch)
+{
+    return p->img[((size_t)y * p->W + reflect_idx(c - p->pad_left, p->W)) * 3 + ch];
+}
+
+static void scharr_x_padded(const padded_img_t* p, float* grad /* H x (W+pad) x 3 */)
+{
+    const int Wb = p->W + p->pad_left, H = p->H;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++) {
+        int ym = reflect101_idx(y - 1, H), yp = reflect101_idx(y + 1, H);
+        for (int c = 0; c < Wb; c++) {
+            int cm = reflect101_idx(c - 1, Wb), cp = reflect101_idx(c + 1, Wb);
+            for (int ch = 0; ch < 3; ch++) {
+                int v = 3 * (padded_px(p, ym, cp, ch) - padded_px(p, ym, cm, ch)) +
+                        10 * (padded_px(p, y, cp, ch) - padded_px(p, y, cm, ch)) +
+                        3 * (padded_px(p, yp, cp, ch) - padded_px(p, yp, cm, ch));
+                grad[((size_t)y * Wb + c) * 3 + ch] = (float)v;
+            }
+        }
+    }
+}
+
+/* One TAD C+G value, M.cpp:455-484, from the three u8 colour abs-diffs and the three f32
+ * gradient abs-diffs.  Exposed for known-answer tests K3/K4. */
+float orc_similarity_pixel(int c0, int c1, int c2, float g0, float g1, float g2, double regularity,
+                           double thresC, double thresG)
+{
+    /* colour term, u8 (M.cpp:459-465, App. B-5) */
+    int color = mean3_u8(c0, c1, c2);
+    int maskC = ((double)color > thresC) ? 1 : 0; /* compare(>thresC)/255 */
+    /* color_.mul(mask) + thresC*(mask): addWeighted(m1,1,mask255,thresC/255) in float, cvRound,
+     * saturate_cast<uchar> */
+    float tf = (float)(color * maskC) * 1.0f + 255.0f * (float)maskC * (float)(thresC * (1.0 / 255.0));
+    long cc_l = lrintf(tf);
+    if (cc_l > 255) cc_l = 255;
+    if (cc_l < 0) cc_l = 0;
+    float cc = (float)cc_l; /* convertTo(CV_32FC1) */
+
+    /* gradient term, f32 (M.cpp:470-482, App. B-6) */
+    const float third = (float)(1.0 / 3.0);
+    float g01 = g0 + g1;                 /* cv::add, exact (integers) */
+    float g = g01 * third + g2 * third;  /* addWeighted 32f, float scalars, not fused (A-8) */
+    int maskG = ((double)g > thresG) ? 1 : 0;
+    float bit = (float)maskG;                   /* compare/255 -> 0/1 */
+    float bit_not = (float)(255 - maskG);       /* bitwise_not of a 0/1 u8 mask: 255 or 254 */
+    float gm = g * bit;                         /* curGridient_.mul(bitImg) */
+    float cg = bit_not * (float)thresG + gm;    /* scaleAdd(bit_not, thresG, gm) */
+
+    /* regularityR*cc + regularity*cg: addWeighted 32f (M.cpp:484) */
+    float rr = (float)(1.0 - regularity), rg = (float)regularity;
+    return cc * rr + cg * rg;
+}
+
+/* computeSimilarity, M.cpp:415-636.  Only the DISPARITY_LEFT + 3-channel branch (437-487)
+ * can execute in the reference (App. B-7).  cost: numD planes H x W f32. */
+int orc_compute_similarity(const uint8_t* L, const uint8_t* R, int H, int W, int C, double regularity,
+                           double thresC, double thresG, int disp_type, int minD, int numD, float* cost)
+{
+    if (C != 3 || disp_type != DISPARITY_LEFT) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    const int max_off = minD + numD - 1; /* M.cpp:422-423 */
+    const int Wb = W + max_off;
+    float* gL = (float*)malloc((size_t)H * W * 3 * sizeof(float));
+    float* gR = (float*)malloc((size_t)H * Wb * 3 * sizeof(float));
+    if (!gL || !gR) { free(gL); free(gR); return ORC_ERR_ALLOC; }
+    padded_img_t pl = {L, H, W, 0}, pr = {R, H, W, max_off};
+    scharr_x_padded(&pl, gL); /* M.cpp:449 */
+    scharr_x_padded(&pr, gR); /* M.cpp:450: gradient of the PADDED right image */
+
+    for (int k = 0; k < numD; k++) {
+        const int off = minD + k;
+        float* out = cost + (size_t)k * H * W;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {
+                const uint8_t* a = L + ((size_t)y * W + x) * 3;
+                const int cb = max_off - off + x; /* column in the padded right image, M.cpp:455 */
+                const uint8_t* b = R + ((size_t)y * W + reflect_idx(cb - max_off, W)) * 3;
+                const float* ga = gL + ((size_t)y * W + x) * 3;
+                const float* gb = gR + ((size_t)y * Wb + cb) * 3;
+                out[(size_t)y * W + x] = orc_similarity_pixel(
+                    absdiff_u8(a[0], b[0]), absdiff_u8(a[1], b[1]), absdiff_u8(a[2], b[2]),
+                    fabsf(ga[0] - gb[0]), fabsf(ga[1] - gb[1]), fabsf(ga[2] - gb[2]), regularity, thresC,
+                    thresG);
+            }
+        }
+    }
+    free(gL);
+    free(gR);
+    return ORC_OK;
+}
+
+/* computeSimilarity padded overload, M.cpp:651-668: every plane REFLECT-padded by win/2.
+ * cost: numD planes (H+2h) x (W+2h). */
+int orc_compute_similarity_padded(const uint8_t* L, const uint8_t* R, int H, int W, int C, double regularity,
+                                  double thresC, double thresG, int disp_type, int win, int minD, int numD,
+                                  float* cost)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW;
+    const int h = win / 2, Hp = H + 2 * h, Wp = W + 2 * h;
+    float* raw = (float*)malloc((size_t)numD * H * W * sizeof(float));
+    if (!raw) return ORC_ERR_ALLOC;
+    int rc = orc_compute_similarity(L, R, H, W, C, regularity, thresC, thresG, disp_type, minD, numD, raw);
+    if (rc == ORC_OK) {
+        for (int k = 0; k < numD; k++)
+            for (int y = 0; y < Hp; y++)
+                for (int x = 0; x < Wp; x++)
+                    cost[((size_t)k * Hp + y) * Wp + x] =
+                        raw[((size_t)k * H + reflect_idx(y - h, H)) * W + reflect_idx(x - h, W)];
+    }
+    free(raw);
+    return rc;
+}
+
+/* boxFilter(src CV_32F -> CV_32F, Size(k,k), normalize=true, BORDER_REFLECT_101), single plane
+ * with a pixel stride so interleaved channels can be filtered in place (A-9).
+ * mode 0: canonical definition used for parity -- f64 window sum, rows of horizontal sums added
+ *         in ascending order, one multiply by 1/(k*k) in f64, one rounding to f32.
+ * mode 1: OpenCV's portable RowSum<float,double> + ColumnSum<double,float> sliding sums,
+ *         literally (kept to measure how far the canonical definition is from it). */
+static int g_box_mode = 0;
+void orc_set_box_mode(int mode) { g_box_mode = mode; }
+
+static void box_filter_plane(const float* src, int sstride, float* dst, int dstride, int H, int W, int k)
+{
+    const int h = k / 2; /* anchor = centre; for even k OpenCV's anchor is k/2 as well */
+    const double scale = 1.0 / ((double)k * k);
+    double* rows = (double*)malloc((size_t)H * W * sizeof(double));
+    if (g_box_mode == 0) {
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                double s = 0;
+                for (int i = 0; i < k; i++) s += (double)src[((size_t)y * W + reflect101_idx(x - h + i, W)) * sstride];
+                rows[(size_t)y * W + x] = s;
+            }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                double s = 0;
+                for (int j = 0; j < k; j++) s += rows[(size_t)reflect101_idx(y - h + j, H) * W + x];
+                dst[((size_t)y * W + x) * dstride] = (float)(s * scale);
+            }
+    } else {
+        /* RowSum: s = sum of first k; then s += S[i+k] - S[i] */
+        for (int y = 0; y < H; y++) {
+            double s = 0;
+            for (int i = 0; i < k; i++) s += (double)src[((size_t)y * W + reflect101_idx(-h + i, W)) * sstride];
+            rows[(size_t)y * W] = s;
+            for (int x = 0; x < W - 1; x++) {
+                s += (double)src[((size_t)y * W + reflect101_idx(x - h + k, W)) * sstride] -
+                     (double)src[((size_t)y * W + reflect101_idx(x - h, W)) * sstride];
+                rows[(size_t)y * W + x + 1] = s;
+            }
+        }
+        /* ColumnSum: SUM = first k-1 rows; per output row: s0 = SUM + Sp; D = s0*scale; SUM = s0 - Sm */
+        double* SUM = (double*)calloc((size_t)W, sizeof(double));
+        for (int j = 0; j < k - 1; j++) {
+            const double* Sp = rows + (size_t)reflect101_idx(-h + j, H) * W;
+            for (int x = 0; x < W; x++) SUM[x] += Sp[x];
+        }
+        for (int y = 0; y < H; y++) {
+            const double* Sp = rows + (size_t)reflect101_idx(y - h + k - 1, H) * W;
+            const double* Sm = rows + (size_t)reflect101_idx(y - h, H) * W;
+            for (int x = 0; x < W; x++) {
+                double s0 = SUM[x] + Sp[x];
+                dst[((size_t)y * W + x) * dstride] = (float)(s0 * scale);
+                SUM[x] = s0 - Sm[x];
+            }
+        }
+        free(SUM);
+    }
+    free(rows);
+}
+
+/* public single-plane box filter for tests */
+void orc_box_filter(const float* src, float* dst, int H, int W, int k)
+{
+    float* tmp = (float*)malloc((size_t)H * W * sizeof(float));
+    box_filter_plane(src, 1, tmp, 1, H, W, k);
+    memcpy(dst, tmp, (size_t)H * W * sizeof(float));
+    free(tmp);
+}
+
+/* getCostSAD_d for DISPARITY_LEFT / RIGHT over all disparities, M.cpp:2442-2503 as called from
+ * M.cpp:2884-2889 / 2893-2898: gray abs-diff (right image read through the REFLECT pad), to f32,
+ * normalised win x win box mean.  cost: numD planes H x W f32. */
+int orc_cost_sad(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, int win, int minD, int numD,
+                 float* cost)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* M.cpp:2458-2462 */
+    uint8_t* gl = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* gr = (uint8_t*)malloc((size_t)H * W);
+    float* diff = (float*)malloc((size_t)H * W * sizeof(float));
+    if (!gl || !gr || !diff) { free(gl); free(gr); free(diff); return ORC_ERR_ALLOC; }
+    /* cvtColor of the padded image == padding of the gray image (per-pixel op) */
+    orc_bgr2gray(L, H, W, gl);
+    orc_bgr2gray(R, H, W, gr);
+    for (int k = 0; k < numD; k++) {
+        const int d = minD + k;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                int a, b;
+                if (disp_type == DISPARITY_LEFT) { /* M.cpp:2477 */
+                    a = gl[(size_t)y * W + x];
+                    b = gr[(size_t)y * W + reflect_idx(x - d, W)];
+                } else { /* M.cpp:2492 */
+                    a = gl[(size_t)y * W + reflect_idx(x + d, W)];
+                    b = gr[(size_t)y * W + x];
+                }
+                diff[(size_t)y * W + x] = (float)absdiff_u8(a, b);
+            }
+        box_filter_plane(diff, 1, cost + (size_t)k * H * W, 1, H, W, win); /* M.cpp:2480 */
+    }
+    free(gl); free(gr); free(diff);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * WTA (M.cpp:1144-1150, 2945-2961, 3032-3048, 3365-3381): strict '<' against DBL_MAX in
+ * ascending d; NaN never selected.  The reference leaves never-updated pixels uninitialised
+ * (App. B-16); this build defines them as 0.
+ * ------------------------------------------------------------------------------------- */
+void orc_wta(const float* volume, int nD, int H, int W, int minD, float* disp)
+{
+    for (size_t p = 0; p < (size_t)H * W; p++) {
+        double best = DBL_MAX;
+        float bd = 0.0f;
+        for (int k = 0; k < nD; k++) {
+            double c = (double)volume[(size_t)k * H * W + p];
+            if (c < best) { best = c; bd = (float)(k + minD); }
+        }
+        disp[p] = bd;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Classic bilateral ASW, computeAdaptiveWeight, M.cpp:1016-1156
+ * ------------------------------------------------------------------------------------- */
+
+/* The (win*win-1)-entry tap list of the reference, with both of its index conventions:
+ * weight direction (dxw,dyw) from the build loops M.cpp:1044-1053, sample offset (dxs,dys) from
+ * the consume loop M.cpp:1088-1102 (transposed + centre quirk, App. B-2). */
+void orc_classic_taps(int ks, int* dxw, int* dyw, int* dxs, int* dys)
+{
+    int h = ks / 2, n = 0;
+    for (int j = -h; j < h + 1; j++)
+        for (int i = -h; i < h + 1; i++) {
+            if (i == 0 && j == 0) continue;
+            dxw[n] = i;
+            dyw[n] = j;
+            n++;
+        }
+    for (int i = 0; i < ks * ks - 1; i++) {
+        int kx, ky;
+        if (i > ks * ks / 2) { kx = (i + 1) / ks; ky = (i + 1) % ks; }
+        else { kx = i / ks; ky = i % ks; }
+        dxs[i] = -h + kx;
+        dys[i] = -h + ky;
+    }
+}
+
+/* Literal restatement: materialises the 2*(win^2-1) weight maps exactly as M.cpp:1041-1072 does.
+ * Memory = 2*(win*win-1)*H*W*4 bytes, so small images only.  vol (optional) receives (float)E,
+ * (numD+1) planes. */
+int orc_asw_classic_literal(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, double gamma_c,
+                            double gamma_g, int disp_type, int win, int minD, int numD, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* build decision: the reference has no guard */
+    const int ks = win, nt = ks * ks - 1;
+    const int max_offset = minD + numD, min_offset = minD; /* M.cpp:1021-1022: inclusive, B-1 */
+    const double k = 3;
+    uint8_t* left = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* right = (uint8_t*)malloc((size_t)H * W);
+    float* wl = (float*)malloc((size_t)nt * H * W * sizeof(float));
+    float* wr = (float*)malloc((size_t)nt * H * W * sizeof(float));
+    double* min_asw = (double*)malloc((size_t)H * W * sizeof(double));
+    if (!left || !right || !wl || !wr || !min_asw) { free(left); free(right); free(wl); free(wr); free(min_asw); return ORC_ERR_ALLOC; }
+    orc_bgr2gray(Lbgr, H, W, left);
+    orc_bgr2gray(Rbgr, H, W, right);
+    for (size_t p = 0; p < (size_t)H * W; p++) { min_asw[p] = DBL_MAX; disp[p] = 0.0f; }
+
+    int n = 0;
+    for (int j = -ks / 2; j < ks / 2 + 1; j++)
+        for (int i = -ks / 2; i < ks / 2 + 1; i++) {
+            if (i == 0 && j == 0) continue;
+            double delta_g = sqrt((double)(i * i + j * j));
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    int nx = imin(imax(0, x + i), W - 1), ny = imin(imax(0, y + j), H - 1);
+                    double dc1 = fabs((double)(left[(size_t)ny * W + nx] - left[(size_t)y * W + x]));
+                    double dc2 = fabs((double)(right[(size_t)ny * W + nx] - right[(size_t)y * W + x]));
+                    wl[((size_t)n * H + y) * W + x] = (float)(k * exp(-(dc1 / gamma_c + delta_g / gamma_g)));
+                    wr[((size_t)n * H + y) * W + x] = (float)(k * exp(-(dc2 / gamma_c + delta_g / gamma_g)));
+                }
+            n++;
+        }
+
+    for (int offset = min_offset; offset <= max_offset; offset++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                double numerator = 0, denominator = 0;
+                for (int i = 0; i < ks * ks - 1; i++) {
+                    int kx, ky;
+                    if (i > ks * ks / 2) { kx = (i + 1) / ks; ky = (i + 1) % ks; }
+                    else { kx = i / ks; ky = i % ks; }
+                    int nx = imin(imax(0, x - ks / 2 + kx), W - 1);
+                    int ny = imin(imax(0, y - ks / 2 + ky), H - 1);
+                    if (disp_type == DISPARITY_LEFT) { /* M.cpp:1104-1108 */
+                        float a = wl[((size_t)i * H + y) * W + x];
+                        float b = wr[((size_t)i * H + y) * W + imax(0, x - offset)];
+                        float ab = a * b; /* float*float stays float in C++ */
+                        numerator += ab * fabs((double)(left[(size_t)ny * W + nx] - right[(size_t)ny * W + imax(0, nx - offset)]));
+                        denominator += ab;
+                    } else { /* M.cpp:1134-1138 */
+                        float a = wl[((size_t)i * H + y) * W + imin(x + offset, W - 1)];
+                        float b = wr[((size_t)i * H + y) * W + x];
+                        float ab = a * b;
+                        numerator += ab * fabs((double)(right[(size_t)ny * W + nx] - left[(size_t)ny * W + imin(nx + offset, W - 1)]));
+                        denominator += ab;
+                    }
+                }
+                double E = numerator / denominator;
+                if (vol) vol[((size_t)(offset - min_offset) * H + y) * W + x] = (float)E;
+                if (E < min_asw[(size_t)y * W + x]) { /* M.cpp:1145-1150 */
+                    min_asw[(size_t)y * W + x] = E;
+                    disp[(size_t)y * W + x] = (float)offset;
+                }
+            }
+    free(left); free(right); free(wl); free(wr); free(min_asw);
+    return ORC_OK;
+}
+
+/* Second, independent restatement: weights looked up from a [dist-class][delta_c] table built
+ * with the reference's expression (M.cpp:1054,1065), nothing materialised, rows in parallel.
+ * Same tap order per (pixel, d), so E is bit-identical to the literal version.  This is the
+ * version the CPU baseline times.  y0,y1: row range to compute (for bounded samples). */
+int orc_asw_classic_rows(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, double gamma_c, double gamma_g,
+                         int disp_type, int win, int minD, int numD, int y0, int y1, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW;
+    const int ks = win, nt = ks * ks - 1, h = ks / 2;
+    const int nD = numD + 1;
+    uint8_t* left = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* right = (uint8_t*)malloc((size_t)H * W);
+    int* taps = (int*)malloc((size_t)nt * 4 * sizeof(int));
+    const int nr2 = 2 * h * h + 1; /* table indexed by i*i+j*j directly */
+    float* lut = (float*)malloc((size_t)nr2 * 256 * sizeof(float));
+    if (!left || !right || !taps || !lut) { free(left); free(right); free(taps); free(lut); return ORC_ERR_ALLOC; }
+    int *dxw = taps, *dyw = taps + nt, *dxs = taps + 2 * nt, *dys = taps + 3 * nt;
+    orc_classic_taps(ks, dxw, dyw, dxs, dys);
+    orc_bgr2gray(Lbgr, H, W, left);
+    orc_bgr2gray(Rbgr, H, W, right);
+    for (int r2 = 0; r2 < nr2; r2++) {
+        double delta_g = sqrt((double)r2);
+        for (int dc = 0; dc < 256; dc++)
+            lut[r2 * 256 + dc] = (float)(3.0 * exp(-((double)dc / gamma_c + delta_g / gamma_g)));
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < W; x++) {
+            double best = DBL_MAX;
+            float bd = 0.0f;
+            for (int k = 0; k < nD; k++) {
+                const int offset = minD + k;
+                double numerator = 0, denominator = 0;
+                for (int i = 0; i < nt; i++) {
+                    const int r2 = dxw[i] * dxw[i] + dyw[i] * dyw[i];
+                    const int nx = imin(imax(0, x + dxs[i]), W - 1), ny = imin(imax(0, y + dys[i]), H - 1);
+                    float a, b;
+                    double c;
+                    if (disp_type == DISPARITY_LEFT) {
+                        const int xr = imax(0, x - offset);
+                        const int wnx = imin(imax(0, x + dxw[i]), W - 1), wny = imin(imax(0, y + dyw[i]), H - 1);
+                        const int rnx = imin(imax(0, xr + dxw[i]), W - 1);
+                        a = lut[r2 * 256 + absdiff_u8(left[(size_t)wny * W + wnx], left[(size_t)y * W + x])];
+                        b = lut[r2 * 256 + absdiff_u8(right[(size_t)wny * W + rnx], right[(size_t)y * W + xr])];
+                        c = (double)absdiff_u8(left[(size_t)ny * W + nx], right[(size_t)ny * W + imax(0, nx - offset)]);
+                    } else {
+                        const int xl = imin(x + offset, W - 1);
+                        const int wny = imin(imax(0, y + dyw[i]), H - 1);
+                        const int lnx = imin(imax(0, xl + dxw[i]), W - 1), rnx = imin(imax(0, x + dxw[i]), W - 1);
+                        a = lut[r2 * 256 + absdiff_u8(left[(size_t)wny * W + lnx], left[(size_t)y * W + xl])];
+                        b = lut[r2 * 256 + absdiff_u8(right[(size_t)wny * W + rnx], right[(size_t)y * W + x])];
+                        c = (double)absdiff_u8(right[(size_t)ny * W + nx], left[(size_t)ny * W + imin(nx + offset, W - 1)]);
+                    }
+                    float ab = a * b;
+                    numerator += ab * c;
+                    denominator += ab;
+                }
+                double E = numerator / denominator;
+                if (vol) vol[((size_t)k * H + y) * W + x] = (float)E;
+                if (E < best) { best = E; bd = (float)offset; }
+            }
+            disp[(size_t)y * W + x] = bd;
+        }
+    }
+    free(left); free(right); free(taps); free(lut);
+    return ORC_OK;
+}
+
+int orc_asw_classic(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, double gamma_c, double gamma_g,
+                    int disp_type, int win, int minD, int numD, float* disp, float* vol)
+{
+    return orc_asw_classic_rows(Lbgr, Rbgr, H, W, gamma_c, gamma_g, disp_type, win, minD, numD, 0, H, disp, vol);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Geodesic ASW, M.cpp:1321-1534
+ * ------------------------------------------------------------------------------------- */
+
+static inline float color_dist(const uint8_t* a, const uint8_t* b) /* getColorDist M.cpp:1321-1326 */
+{
+    return (float)(fabs((double)(a[0] - b[0])) + fabs((double)(a[1] - b[1])) + fabs((double)(a[2] - b[2])));
+}
+
+/* getWinGeoDist, M.cpp:1328-1390, on one (win+2)^2 window.  img(r,c) -> pointer to BGR. */
+static void win_geo_dist(const uint8_t* img, int H, int W, int px, int py, int win, int iterTime, float* wd)
+{
+    const int h = win / 2, n = win + 2;
+#define WIMG(r, c) (img + ((size_t)reflect_idx(py - h - 1 + (r), H) * W + reflect_idx(px - h - 1 + (c), W)) * 3)
+#define WD(r, c) wd[(r) * n + (c)]
+    for (int it = 0; it < iterTime; it++) {
+        if (it / 2 == 1) { /* forward raster: L, UL, U, UR  (M.cpp:1341-1364) */
+            for (int r = 1; r <= win; r++)
+                for (int c = 1; c <= win; c++) {
+                    float v;
+                    v = WD(r, c - 1) + color_dist(WIMG(r, c - 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r - 1, c - 1) + color_dist(WIMG(r - 1, c - 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r - 1, c) + color_dist(WIMG(r - 1, c), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r - 1, c + 1) + color_dist(WIMG(r - 1, c + 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                }
+        } else if (it / 2 == 0) { /* backward raster: R, BR, B, BL  (M.cpp:1365-1388) */
+            for (int r = win; r > 0; r--)
+                for (int c = win; c > 0; c--) {
+                    float v;
+                    v = WD(r, c + 1) + color_dist(WIMG(r, c + 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r + 1, c + 1) + color_dist(WIMG(r + 1, c + 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r + 1, c) + color_dist(WIMG(r + 1, c), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                    v = WD(r + 1, c - 1) + color_dist(WIMG(r + 1, c - 1), WIMG(r, c));
+                    WD(r, c) = fminf(WD(r, c), v);
+                }
+        }
+    }
+#undef WIMG
+#undef WD
+}
+
+/* getGeodesicDist, M.cpp:1392-1424.  out[(y*W+x)*win*win + j*win + i]. */
+int orc_geodesic_dist(const uint8_t* img, int H, int W, int win, int iterTime, float* out)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW;
+    const int h = win / 2, n = win + 2;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++) {
+        float* wd = (float*)malloc((size_t)n * n * sizeof(float));
+        for (int x = 0; x < W; x++) {
+            for (int q = 0; q < n * n; q++) wd[q] = FLT_MAX; /* M.cpp:1416 */
+            wd[(h + 1) * n + (h + 1)] = 0;                    /* M.cpp:1417 */
+            win_geo_dist(img, H, W, x, y, win, iterTime, wd);
+            float* o = out + ((size_t)y * W + x) * win * win;
+            for (int j = 0; j < win; j++)
+                for (int i = 0; i < win; i++) o[j * win + i] = wd[(j + 1) * n + (i + 1)]; /* M.cpp:1420-1421 */
+        }
+        free(wd);
+    }
+    return ORC_OK;
+}
+
+/* computeAdaptiveWeight_geodesic, M.cpp:1436-1534. */
+int orc_asw_geodesic(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, int win, int minD, int numD,
+                     float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* M.cpp:1440-1443 */
+    const int ks = win, h = ks / 2, nD = numD + 1; /* inclusive range, M.cpp:1447,1467 */
+    float* wL = (float*)malloc((size_t)H * W * ks * ks * sizeof(float));
+    float* wR = (float*)malloc((size_t)H * W * ks * ks * sizeof(float));
+    if (!wL || !wR) { free(wL); free(wR); return ORC_ERR_ALLOC; }
+    orc_geodesic_dist(L, H, W, win, 3, wL); /* M.cpp:1464 */
+    orc_geodesic_dist(R, H, W, win, 3, wR); /* M.cpp:1465 */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double best = DBL_MAX;
+            float bd = 0.0f;
+            for (int k = 0; k < nD; k++) {
+                const int offset = minD + k;
+                double numerator = 0, denominator = 0;
+                const float *pl, *pr;
+                if (disp_type == DISPARITY_LEFT) {
+                    pl = wL + ((size_t)y * W + x) * ks * ks;
+                    pr = wR + ((size_t)y * W + imax(0, x - offset)) * ks * ks;
+                } else {
+                    pl = wL + ((size_t)y * W + imin(x + offset, W - 1)) * ks * ks;
+                    pr = wR + ((size_t)y * W + x) * ks * ks;
+                }
+                for (int j = 0; j < ks; j++)
+                    for (int i = 0; i < ks; i++) {
+                        int nx = imin(imax(0, x - h + i), W - 1), ny = imin(imax(0, y - h + j), H - 1);
+                        float c;
+                        if (disp_type == DISPARITY_LEFT)
+                            c = color_dist(L + ((size_t)ny * W + nx) * 3, R + ((size_t)ny * W + imax(0, nx - offset)) * 3);
+                        else
+                            c = color_dist(R + ((size_t)ny * W + nx) * 3, L + ((size_t)ny * W + imin(W - 1, nx + offset)) * 3);
+                        float ab = pl[j * ks + i] * pr[j * ks + i]; /* f32 product */
+                        float abc = ab * c;                         /* f32 product, M.cpp:1488-1490 */
+                        numerator += abc;
+                        denominator += ab;
+                    }
+                double E = numerator / denominator;
+                if (vol) vol[((size_t)k * H + y) * W + x] = (float)E;
+                if (E < best) { best = E; bd = (float)offset; }
+            }
+            disp[(size_t)y * W + x] = bd;
+        }
+    free(wL); free(wR);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Guided filter, M.cpp:2727-2854, and the two ASW variants built on it
+ * ------------------------------------------------------------------------------------- */
+
+/* normalize(src, dst, 0, 1, NORM_MINMAX, CV_32F) parameters (A-10): returns float scale/shift */
+static void minmax_scale(double smin, double smax, float* a, float* b)
+{
+    double scale = (smax - smin > DBL_EPSILON) ? 1.0 / (smax - smin) : 0.0;
+    double shift = 0.0 - smin * scale;
+    *a = (float)scale;
+    *b = (float)shift;
+}
+
+/* getGuidedFilter(guidedImg 8U C-channel, inputP f32, r, eps) -> q f32.  C must be 3 or 6
+ * (multiChl_to_oneChl_mul returns an empty Mat otherwise, M.cpp:2732-2734). */
+int orc_guided_filter(const uint8_t* guide, int C, const float* P_in, int H, int W, int r, double eps, float* q)
+{
+    if (C != 3 && C != 6) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    const size_t N = (size_t)H * W;
+    float* I = (float*)malloc(N * C * sizeof(float));
+    float* P = (float*)malloc(N * sizeof(float));
+    float* meanI = (float*)malloc(N * C * sizeof(float));
+    float* meanP = (float*)malloc(N * sizeof(float));
+    float* corrIP = (float*)malloc(N * C * sizeof(float));
+    float* corrI = (float*)malloc(N * C * sizeof(float));
+    float* tmp = (float*)malloc(N * sizeof(float));
+    float* a = (float*)malloc(N * C * sizeof(float));
+    float* b = (float*)malloc(N * sizeof(float));
+    if (!I || !P || !meanI || !meanP || !corrIP || !corrI || !tmp || !a || !b) {
+        free(I); free(P); free(meanI); free(meanP); free(corrIP); free(corrI); free(tmp); free(a); free(b);
+        return ORC_ERR_ALLOC;
+    }
+    /* M.cpp:2774: min/max over ALL channels of the guide */
+    {
+        int mn = 255, mx = 0;
+        for (size_t i = 0; i < N * C; i++) { if (guide[i] < mn) mn = guide[i]; if (guide[i] > mx) mx = guide[i]; }
+        float sa, sb;
+        minmax_scale(mn, mx, &sa, &sb);
+        for (size_t i = 0; i < N * C; i++) I[i] = (float)guide[i] * sa + sb; /* convertTo 8u->32f, float a,b */
+    }
+    /* M.cpp:2775: per-call (= per disparity slice) min/max of P */
+    {
+        float mn = P_in[0], mx = P_in[0];
+        for (size_t i = 1; i < N; i++) { if (P_in[i] < mn) mn = P_in[i]; if (P_in[i] > mx) mx = P_in[i]; }
+        float sa, sb;
+        minmax_scale((double)mn, (double)mx, &sa, &sb);
+        for (size_t i = 0; i < N; i++) P[i] = P_in[i] * sa + sb;
+    }
+    for (int c = 0; c < C; c++) box_filter_plane(I + c, C, meanI + c, C, H, W, r); /* M.cpp:2778 */
+    box_filter_plane(P, 1, meanP, 1, H, W, r);                                     /* M.cpp:2780 */
+    for (int c = 0; c < C; c++) {                                                  /* M.cpp:2787-2792 */
+        for (size_t i = 0; i < N; i++) tmp[i] = I[i * C + c] * P[i];
+        box_filter_plane(tmp, 1, corrIP + c, C, H, W, r);
+    }
+    for (int c = 0; c < C; c++) {                                                  /* M.cpp:2796 */
+        for (size_t i = 0; i < N; i++) tmp[i] = I[i * C + c] * I[i * C + c];
+        box_filter_plane(tmp, 1, corrI + c, C, H, W, r);
+    }
+    const float epsf = (float)eps;
+    for (size_t i = 0; i < N; i++) {
+        float dot = 0.0f;
+        for (int c = 0; c < C; c++) {
+            float mI = meanI[i * C + c];
+            float mm = mI * mI;
+            float var = corrI[i * C + c] - mm;            /* M.cpp:2799 */
+            float mp = mI * meanP[i];                     /* M.cpp:2809 */
+            float cov = corrIP[i * C + c] - mp;           /* M.cpp:2815 */
+            float den = 1.0f * epsf + var;                /* scaleAdd(ones, eps, var) */
+            float ac = cov / den;                         /* M.cpp:2846 (A-11) */
+            a[i * C + c] = ac;
+            float pr = ac * mI;                           /* operator* Vec, M.cpp:22-31: left-to-right */
+            dot = (c == 0) ? pr : dot + pr;
+        }
+        b[i] = meanP[i] - dot;                            /* M.cpp:2847 */
+    }
+    for (int c = 0; c < C; c++) {                                                  /* M.cpp:2849 */
+        for (size_t i = 0; i < N; i++) tmp[i] = a[i * C + c];
+        box_filter_plane(tmp, 1, a + c, C, H, W, r);
+    }
+    memcpy(tmp, b, N * sizeof(float));
+    box_filter_plane(tmp, 1, b, 1, H, W, r);                                       /* M.cpp:2850 */
+    for (size_t i = 0; i < N; i++) {                                               /* M.cpp:2852 */
+        float dot = 0.0f;
+        for (int c = 0; c < C; c++) {
+            float pr = a[i * C + c] * I[i * C + c];
+            dot = (c == 0) ? pr : dot + pr;
+        }
+        q[i] = dot + b[i];
+    }
+    free(I); free(P); free(meanI); free(meanP); free(corrIP); free(corrI); free(tmp); free(a); free(b);
+    return ORC_OK;
+}
+
+/* computeAdaptiveWeight_GuidedF_2, M.cpp:2976-3050: TAD C+G cost, guide = left image. */
+int orc_asw_guided2(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, double eps, int win, int minD,
+                    int numD, float* disp, float* vol)
+{
+    if (disp_type != DISPARITY_LEFT) return ORC_ERR_UNSUPPORTED_LAYOUT; /* App. B-7 */
+    const size_t N = (size_t)H * W;
+    float* costs = (float*)malloc((size_t)numD * N * sizeof(float));
+    float* qv = vol ? vol : (float*)malloc((size_t)numD * N * sizeof(float));
+    if (!costs || !qv) { free(costs); if (!vol) free(qv); return ORC_ERR_ALLOC; }
+    int rc = orc_compute_similarity(L, R, H, W, 3, 0.4, 10, 50, disp_type, minD, numD, costs); /* M.cpp:2990 */
+    if (rc == ORC_OK) {
+        for (int i = 0; i < numD && rc == ORC_OK; i++) /* M.cpp:2995-3006 */
+            rc = orc_guided_filter(L, 3, costs + (size_t)i * N, H, W, win, eps, qv + (size_t)i * N);
+        if (rc == ORC_OK) orc_wta(qv, numD, H, W, minD, disp); /* M.cpp:3032-3048 */
+    }
+    free(costs);
+    if (!vol) free(qv);
+    return rc;
+}
+
+/* computeAdaptiveWeight_GuidedF, M.cpp:2867-2963: SAD cost, 6-channel guide [L, R shifted by d]. */
+int orc_asw_guided(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, double eps, int win, int minD,
+                   int numD, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW;
+    const size_t N = (size_t)H * W;
+    float* costs = (float*)malloc((size_t)numD * N * sizeof(float));
+    float* qv = vol ? vol : (float*)malloc((size_t)numD * N * sizeof(float));
+    uint8_t* guide = (uint8_t*)malloc(N * 6);
+    if (!costs || !qv || !guide) { free(costs); if (!vol) free(qv); free(guide); return ORC_ERR_ALLOC; }
+    int rc = orc_cost_sad(L, R, H, W, disp_type, win, minD, numD, costs); /* M.cpp:2884-2898 */
+    for (int i = 0; i < numD && rc == ORC_OK; i++) {
+        const int d = minD + i;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const uint8_t *pl, *pr;
+                if (disp_type == DISPARITY_LEFT) { /* M.cpp:2908-2912: Rect(numDisparity-i-1) == shift by d */
+                    pl = L + ((size_t)y * W + x) * 3;
+                    pr = R + ((size_t)y * W + reflect_idx(x - d, W)) * 3;
+                } else { /* M.cpp:2925-2929 */
+                    pl = L + ((size_t)y * W + reflect_idx(x + d, W)) * 3;
+                    pr = R + ((size_t)y * W + x) * 3;
+                }
+                uint8_t* g = guide + ((size_t)y * W + x) * 6;
+                g[0] = pl[0]; g[1] = pl[1]; g[2] = pl[2]; g[3] = pr[0]; g[4] = pr[1]; g[5] = pr[2];
+            }
+        rc = orc_guided_filter(guide, 6, costs + (size_t)i * N, H, W, win, eps, qv + (size_t)i * N);
+    }
+    if (rc == ORC_OK) orc_wta(qv, numD, H, W, minD, disp);
+    free(costs); free(guide);
+    if (!vol) free(qv);
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Weighted-median ASW, M.cpp:3139-3383 (DISPARITY_LEFT; RIGHT is UB in the reference, B-13)
+ * ------------------------------------------------------------------------------------- */
+
+/* colour weight of computeColorWeightGau, M.cpp:3170-3179: exp((d0+d1+d2)/rateR*(-1)) evaluated as
+ * addWeighted(d0+d1, -1/rateR, d2, -1/rateR) in f32, then exp.  cv::exp is restated as expf (A-12). */
+float orc_wm_color_weight(int d0, int d1, int d2, double rateR)
+{
+    const float al = (float)((1.0 / rateR) * (-1.0));
+    float arg = (float)(d0 + d1) * al + (float)d2 * al;
+    return expf(arg);
+}
+
+/* space kernel computeSpaceWeightGau, M.cpp:3207-3226 */
+void orc_wm_space_kernel(int win, double rateS, float* k)
+{
+    const int h = win / 2;
+    const float al = (float)((1.0 / rateS) * (-1.0));
+    for (int y = 0; y < win; y++)
+        for (int x = 0; x < win; x++) {
+            float v = (float)((x - h) * (x - h)) + (float)((y - h) * (y - h));
+            k[x * win + y] = expf(v * al); /* at(x,y): transposed but symmetric, B-14 */
+        }
+}
+
+typedef struct { float c, w; } cw_t;
+
+/* one weighted-median pick, M.cpp:3276-3304.  cw is overwritten (sorted). */
+static float wmedian_pick(cw_t* cw, cw_t* scratch, int n, double halfSum)
+{
+    /* stable insertion sort by cost == std::multimap<float,float> insertion order */
+    (void)scratch;
+    for (int i = 1; i < n; i++) {
+        cw_t v = cw[i];
+        int j = i - 1;
+        while (j >= 0 && cw[j].c > v.c) { cw[j + 1] = cw[j]; j--; }
+        cw[j + 1] = v;
+    }
+    double partial = 0.0;
+    for (int i = 0; i < n; i++) {
+        partial += (double)cw[i].w;
+        if (partial > halfSum) return i == 0 ? cw[0].c : cw[i - 1].c;
+    }
+    return 0.0f; /* never crossed: reference leaves the pixel uninitialised; build value 0 */
+}
+
+float orc_wmedian_pick(const float* cost, const float* weight, int n)
+{
+    cw_t* cw = (cw_t*)malloc((size_t)n * sizeof(cw_t));
+    double s = 0;
+    for (int i = 0; i < n; i++) { cw[i].c = cost[i]; cw[i].w = weight[i]; s += (double)weight[i]; }
+    float r = wmedian_pick(cw, NULL, n, s / 2);
+    free(cw);
+    return r;
+}
+
+int orc_asw_wmedian(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, int win, double rateS,
+                    double rateR, int minD, int numD, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* M.cpp:3238-3241 */
+    if (disp_type != DISPARITY_LEFT) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    const int h = win / 2, n = win * win, Hp = H + 2 * h, Wp = W + 2 * h;
+    const int max_off = minD + numD - 1, Wb = W + max_off;
+    const size_t N = (size_t)H * W;
+    float* costs = (float*)malloc((size_t)numD * Hp * Wp * sizeof(float));
+    float* wv = vol ? vol : (float*)malloc((size_t)numD * N * sizeof(float));
+    float* wd = (float*)malloc((size_t)n * sizeof(float));
+    float* wLw = (float*)malloc(N * n * sizeof(float));
+    float* wRw = (float*)malloc((size_t)H * Wb * n * sizeof(float));
+    if (!costs || !wv || !wd || !wLw || !wRw) { free(costs); if (!vol) free(wv); free(wd); free(wLw); free(wRw); return ORC_ERR_ALLOC; }
+    int rc = orc_compute_similarity_padded(L, R, H, W, 3, 0.4, 10, 50, disp_type, win, minD, numD, costs); /* M.cpp:3250 */
+    if (rc != ORC_OK) { free(costs); if (!vol) free(wv); free(wd); free(wLw); free(wRw); return rc; }
+    orc_wm_space_kernel(win, rateS, wd); /* M.cpp:3255 */
+
+    /* computeColorWeightGau(leftImg): window over the REFLECT(h)-padded image, M.cpp:3156,3165 */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t* c0 = L + ((size_t)y * W + x) * 3;
+            for (int j = 0; j < win; j++)
+                for (int i = 0; i < win; i++) {
+                    const uint8_t* p = L + ((size_t)reflect_idx(y - h + j, H) * W + reflect_idx(x - h + i, W)) * 3;
+                    wLw[((size_t)y * W + x) * n + j * win + i] =
+                        orc_wm_color_weight(absdiff_u8(p[0], c0[0]), absdiff_u8(p[1], c0[1]), absdiff_u8(p[2], c0[2]), rateR);
+                }
+        }
+    /* computeColorWeightGau(rightImg_border): the image is the (W+max_off)-wide REFLECT-left-padded
+     * right image (M.cpp:3246), padded AGAIN by h with REFLECT inside the function (M.cpp:3156). */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int cb = 0; cb < Wb; cb++) {
+            const uint8_t* c0 = R + ((size_t)y * W + reflect_idx(cb - max_off, W)) * 3;
+            for (int j = 0; j < win; j++)
+                for (int i = 0; i < win; i++) {
+                    int cc = reflect_idx(cb - h + i, Wb);
+                    const uint8_t* p = R + ((size_t)reflect_idx(y - h + j, H) * W + reflect_idx(cc - max_off, W)) * 3;
+                    wRw[((size_t)y * Wb + cb) * n + j * win + i] =
+                        orc_wm_color_weight(absdiff_u8(p[0], c0[0]), absdiff_u8(p[1], c0[1]), absdiff_u8(p[2], c0[2]), rateR);
+                }
+        }
+
+    for (int off = 0; off < numD; off++) { /* M.cpp:3264 */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int y = 0; y < H; y++) {
+            cw_t* cw = (cw_t*)malloc((size_t)n * sizeof(cw_t));
+            for (int x = 0; x < W; x++) {
+                const float* pl = wLw + ((size_t)y * W + x) * n;
+                const float* pr = wRw + ((size_t)y * Wb + (x - off + numD - 1)) * n; /* M.cpp:3274 */
+                double sum = 0.0;
+                for (int j = 0; j < win; j++)
+                    for (int i = 0; i < win; i++) {
+                        float w = pl[j * win + i] * wd[j * win + i]; /* .mul(weightDist) */
+                        w = w * pr[j * win + i];                     /* .mul(weightWinsR) */
+                        cw[j * win + i].w = w;
+                        cw[j * win + i].c = costs[((size_t)off * Hp + (y + j)) * Wp + (x + i)]; /* M.cpp:3273 */
+                        sum += (double)w;                            /* cv::sum, f64 (A-13) */
+                    }
+                wv[(size_t)off * N + (size_t)y * W + x] = wmedian_pick(cw, NULL, n, sum / 2);
+            }
+            free(cw);
+        }
+    }
+    orc_wta(wv, numD, H, W, minD, disp); /* M.cpp:3365-3381 */
+    free(costs); free(wd); free(wLw); free(wRw);
+    if (!vol) free(wv);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * stereoMatching selector, M.cpp:46-88, with the literals it hard-codes.
+ * ------------------------------------------------------------------------------------- */
+int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int disparity_type, int algorithm, int win,
+                        int minD, int numD, float* disp)
+{
+    switch (algorithm) {
+    case 2: return orc_asw_classic(L, R, H, W, 30, 20, disparity_type, win, minD, numD, disp, NULL);  /* M.cpp:58 */
+    case 4: return orc_asw_geodesic(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:64 */
+    case 7: return orc_asw_guided(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);      /* M.cpp:73 */
+    case 8: return orc_asw_guided2(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);     /* M.cpp:76 */
+    case 10: return orc_asw_wmedian(L, R, H, W, disparity_type, win, 10, 10, minD, numD, disp, NULL);  /* M.cpp:82 */
+    default: return 3; /* unsupported method (out of scope) */
+    }
+}
