@@ -1,0 +1,315 @@
+"""aswstereomatch_amd -- MI355X-native adaptive-support-weight stereo matching.
+
+Host-side mirror (Python) of the reference's interface for the hot path
+(aswStereoMatch/methods/aswMethods.h, "M.h"): same function names, argument order, defaults
+and enum values; numpy arrays stand where cv::Mat stands (as in OpenCV's own Python binding).
+Everything is computed by hand-written HIP kernels behind the C-ABI of include/asw_mi355x.h;
+there is no CPU fallback -- a missing libasw_mi355x.so raises ImportError at first use.
+
+Error behaviour follows the reference: where the reference returns silently or
+hands back an empty cv::Mat (size mismatch, even window) the mirror returns None / an empty
+list and records the status in ``last_status()``; anything else raises AswError.
+"""
+import ctypes as C
+import enum
+import os
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import AswError, AswImage, AswTiming
+
+__all__ = [
+    "DisparityType", "StereoMatchingAlgorithms", "DISPARITY_LEFT", "DISPARITY_RIGHT", "Context",
+    "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
+    "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
+    "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
+    "AswError",
+]
+
+
+class DisparityType(enum.IntEnum):  # parametersStereo.h:4-8
+    DISPARITY_LEFT = 0
+    DISPARITY_RIGHT = 1
+
+
+class StereoMatchingAlgorithms(enum.IntEnum):  # parametersStereo.h:10-24
+    BM = 0
+    SGBM = 1
+    ADAPTIVE_WEIGHT = 2
+    ADAPTIVE_WEIGHT_8DIRECT = 3
+    ADAPTIVE_WEIGHT_GEODESIC = 4
+    ADAPTIVE_WEIGHT_BILATERAL_GRID = 5
+    ADAPTIVE_WEIGHT_BLO1 = 6
+    ADAPTIVE_WEIGHT_GUIDED_FILTER = 7
+    ADAPTIVE_WEIGHT_GUIDED_FILTER_2 = 8
+    ADAPTIVE_WEIGHT_GUIDED_FILTER_3 = 9
+    ADAPTIVE_WEIGHT_MEDIAN = 10
+    NCC = 11
+
+
+DISPARITY_LEFT = DisparityType.DISPARITY_LEFT
+DISPARITY_RIGHT = DisparityType.DISPARITY_RIGHT
+
+OK, ERR_SIZE_MISMATCH, ERR_EVEN_WINDOW, ERR_UNSUPPORTED_METHOD, ERR_UNSUPPORTED_LAYOUT = 0, 1, 2, 3, 4
+ERR_HIP, ERR_ALLOC, ERR_BAD_ARGUMENT, ERR_NO_FRAME = 5, 6, 7, 8
+# statuses for which the reference returns silently / an empty Mat
+_SILENT = (ERR_SIZE_MISMATCH, ERR_EVEN_WINDOW)
+
+_state = threading.local()
+
+
+def last_status():
+    """Status of the last call made from this thread (0 = ok)."""
+    return getattr(_state, "status", 0)
+
+
+def _image(arr, depth=0):
+    """numpy array -> asw_image (keeps `arr` alive through the returned tuple)."""
+    a = np.asarray(arr)
+    want = np.uint8 if depth == 0 else np.float32
+    if a.dtype != want:
+        raise TypeError("expected %s image, got %s" % (np.dtype(want).name, a.dtype))
+    if a.ndim == 2:
+        ch = 1
+    elif a.ndim == 3:
+        ch = a.shape[2]
+    else:
+        raise ValueError("image must be HxW or HxWxC")
+    if a.strides[-1] != a.itemsize or (a.ndim == 3 and a.strides[1] != ch * a.itemsize):
+        a = np.ascontiguousarray(a)
+    img = AswImage(a.ctypes.data, a.shape[0], a.shape[1], ch, depth, a.strides[0])
+    return img, a
+
+
+class Context:
+    """One device context (asw_create / asw_destroy).  Not shared between threads."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        self._lib = _lib.lib()
+        rc = self._lib.asw_create(int(device_id), C.byref(self._h))
+        if rc != 0:
+            raise AswError(rc, "asw_create(device %d)" % device_id)
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.asw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ----
+    def _finish(self, rc, where):
+        _state.status = rc
+        if rc == 0:
+            return True
+        if rc in _SILENT:
+            return False
+        raise AswError(rc, where)
+
+    @staticmethod
+    def _candidates(algorithm, numDisparity):
+        inclusive = algorithm in (StereoMatchingAlgorithms.ADAPTIVE_WEIGHT, StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_GEODESIC)
+        return numDisparity + (1 if inclusive else 0)
+
+    # ---- whole-method entry point (M.h:91-92) ----
+    def stereoMatching(self, srcLeft, srcRight, disparityType, algorithmType, winSize=15, minDisparity=0,
+                       numDisparity=64, return_cost_volume=False):
+        li, la = _image(srcLeft)
+        ri, ra = _image(srcRight)
+        disp = np.zeros((la.shape[0], la.shape[1]), np.float32)
+        di, _ = _image(disp, 5)
+        vol = None
+        pv = None
+        if return_cost_volume:
+            vol = np.zeros((self._candidates(int(algorithmType), numDisparity), la.shape[0], la.shape[1]), np.float32)
+            pv = vol.ctypes.data_as(C.c_void_p)
+        rc = self._lib.asw_stereo_match(self._h, C.byref(li), C.byref(ri), C.byref(di), int(disparityType),
+                                        int(algorithmType), winSize, minDisparity, numDisparity, pv)
+        if not self._finish(rc, "asw_stereo_match"):
+            return (None, None) if return_cost_volume else None
+        return (disp, vol) if return_cost_volume else disp
+
+    def _aggregate(self, fn, name, n_vol, leftImg, rightImg, args, return_cost_volume):
+        li, la = _image(leftImg)
+        ri, ra = _image(rightImg)
+        disp = np.zeros((la.shape[0], la.shape[1]), np.float32)
+        di, _ = _image(disp, 5)
+        vol, pv = None, None
+        if return_cost_volume:
+            vol = np.zeros((n_vol, la.shape[0], la.shape[1]), np.float32)
+            pv = vol.ctypes.data_as(C.c_void_p)
+        rc = fn(self._h, C.byref(li), C.byref(ri), C.byref(di), *args, pv)
+        if not self._finish(rc, name):
+            return (None, None) if return_cost_volume else None
+        return (disp, vol) if return_cost_volume else disp
+
+    # ---- per-method entry points (M.h:133-182) ----
+    def computeAdaptiveWeight(self, leftImg, rightImg, gamma_c=30, gamma_g=2, dispType=DISPARITY_LEFT, winSize=7,
+                              minDisparity=186, numDisparity=144, return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_bilateral, "asw_aggregate_bilateral", numDisparity + 1, leftImg,
+                               rightImg, (float(gamma_c), float(gamma_g), int(dispType), winSize, minDisparity, numDisparity),
+                               return_cost_volume)
+
+    def computeAdaptiveWeight_geodesic(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=186,
+                                       numDisparity=144, return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_geodesic, "asw_aggregate_geodesic", numDisparity + 1, leftImg,
+                               rightImg, (int(dispType), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeAdaptiveWeight_GuidedF(self, leftImg, rightImg, dispType=DISPARITY_LEFT, eps=1e-8, winSize=35,
+                                      minDisparity=186, numDisparity=144, return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_guided, "asw_aggregate_guided", numDisparity, leftImg, rightImg,
+                               (int(dispType), float(eps), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeAdaptiveWeight_GuidedF_2(self, leftImg, rightImg, dispType=DISPARITY_LEFT, eps=1e-8, winSize=35,
+                                        minDisparity=186, numDisparity=144, return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_guided2, "asw_aggregate_guided2", numDisparity, leftImg, rightImg,
+                               (int(dispType), float(eps), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeAdaptiveWeight_WeightedMedian(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=35,
+                                             sampleRateS=10, sampleRateR=10, minDisparity=186, numDisparity=144,
+                                             return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_wmedian, "asw_aggregate_wmedian", numDisparity, leftImg, rightImg,
+                               (int(dispType), winSize, float(sampleRateS), float(sampleRateR), minDisparity, numDisparity),
+                               return_cost_volume)
+
+    # ---- cost builders (M.h:101-113): return a list of planes like std::vector<cv::Mat> ----
+    def _cost(self, fn, name, leftImg, rightImg, dtype, plane_shape, numDisparity, args):
+        li, la = _image(leftImg)
+        ri, ra = _image(rightImg)
+        out = np.zeros((numDisparity,) + plane_shape, dtype)
+        rc = fn(self._h, C.byref(li), C.byref(ri), out.ctypes.data_as(C.c_void_p), *args)
+        if not self._finish(rc, name):
+            return []  # cost_ds left empty / untouched by the reference
+        return list(out)
+
+    def computeAD(self, leftImg, rightImg, dispType=DISPARITY_LEFT, minDisparity=0, numDisparity=30):
+        a = np.asarray(leftImg)
+        return self._cost(self._lib.asw_cost_ad, "asw_cost_ad", leftImg, rightImg, np.uint8, a.shape[:2], numDisparity,
+                          (int(dispType), minDisparity, numDisparity))
+
+    def computeTAD(self, leftImg, rightImg, dispType=DISPARITY_LEFT, threshold_T=30, minDisparity=0, numDisparity=30):
+        a = np.asarray(leftImg)
+        return self._cost(self._lib.asw_cost_tad, "asw_cost_tad", leftImg, rightImg, np.uint8, a.shape[:2], numDisparity,
+                          (int(dispType), threshold_T, minDisparity, numDisparity))
+
+    def computeSimilarity(self, leftImg, rightImg, regularity, thresC, thresG, dispType, minDisparity, numDisparity,
+                          winSize=None):
+        """Both overloads of computeSimilarity (M.cpp:415, 651); winSize selects the padded one."""
+        a = np.asarray(leftImg)
+        h = 0 if winSize is None else winSize // 2
+        shape = (a.shape[0] + 2 * h, a.shape[1] + 2 * h)
+        return self._cost(self._lib.asw_cost_similarity, "asw_cost_similarity", leftImg, rightImg, np.float32, shape,
+                          numDisparity, (float(regularity), float(thresC), float(thresG), int(dispType),
+                                         0 if winSize is None else winSize, minDisparity, numDisparity))
+
+    def getCostSAD(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=35, minDisparity=0, numDisparity=30):
+        """getCostSAD_d (M.cpp:2442) for every disparity, as M.cpp:2884-2889 calls it."""
+        a = np.asarray(leftImg)
+        return self._cost(self._lib.asw_cost_sad, "asw_cost_sad", leftImg, rightImg, np.float32, a.shape[:2], numDisparity,
+                          (int(dispType), winSize, minDisparity, numDisparity))
+
+    # ---- public building blocks ----
+    def getGuidedFilter(self, guidedImg, inputP, r, eps):
+        gi, ga = _image(guidedImg)
+        p = np.ascontiguousarray(inputP, dtype=np.float32)
+        if p.shape != ga.shape[:2]:
+            _state.status = ERR_SIZE_MISMATCH
+            return None  # M.cpp:2768-2769
+        q = np.zeros_like(p)
+        rc = self._lib.asw_guided_filter(self._h, C.byref(gi), p.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p),
+                                         r, float(eps))
+        return q if self._finish(rc, "asw_guided_filter") else None
+
+    def getGeodesicDist(self, originImg, winSize=15, iterTime=3):
+        ii, ia = _image(originImg)
+        out = np.zeros((ia.shape[0], ia.shape[1], winSize, winSize), np.float32)
+        rc = self._lib.asw_geodesic_dist(self._h, C.byref(ii), out.ctypes.data_as(C.c_void_p), winSize, iterTime)
+        return out if self._finish(rc, "asw_geodesic_dist") else None
+
+    def winnerTakeAll(self, costVolume, minDisparity=0):
+        v = np.ascontiguousarray(costVolume, dtype=np.float32)
+        disp = np.zeros(v.shape[1:], np.float32)
+        rc = self._lib.asw_wta(self._h, v.ctypes.data_as(C.c_void_p), v.shape[0], v.shape[1], v.shape[2], minDisparity,
+                               disp.ctypes.data_as(C.c_void_p))
+        self._finish(rc, "asw_wta")
+        return disp
+
+    def bgr2gray(self, img):
+        ii, ia = _image(img)
+        out = np.zeros(ia.shape[:2], np.uint8)
+        rc = self._lib.asw_bgr2gray(self._h, C.byref(ii), out.ctypes.data_as(C.c_void_p))
+        self._finish(rc, "asw_bgr2gray")
+        return out
+
+    # ---- resident (HBM) API used by bench.py ----
+    def upload_pair(self, slot, left, right):
+        li, la = _image(left)
+        ri, ra = _image(right)
+        self._finish(self._lib.asw_upload_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_upload_pair")
+
+    def match_resident(self, slot, disparityType, algorithmType, winSize, minDisparity, numDisparity, keep_volume=False):
+        rc = self._lib.asw_match_resident(self._h, slot, int(disparityType), int(algorithmType), winSize, minDisparity,
+                                          numDisparity, 1 if keep_volume else 0)
+        self._finish(rc, "asw_match_resident")
+
+    def download_disparity(self, slot, shape):
+        disp = np.zeros(shape, np.float32)
+        di, _ = _image(disp, 5)
+        self._finish(self._lib.asw_download_disparity(self._h, slot, C.byref(di)), "asw_download_disparity")
+        return disp
+
+    def download_volume(self, slot, shape):
+        vol = np.zeros(shape, np.float32)
+        self._finish(self._lib.asw_download_volume(self._h, slot, vol.ctypes.data_as(C.c_void_p), vol.size), "asw_download_volume")
+        return vol
+
+    def timing(self):
+        t = AswTiming()
+        self._lib.asw_get_timing(self._h, C.byref(t))
+        return {"total_ms": t.total_ms, "aggregate_ms": t.aggregate_ms, "cost_ms": t.cost_ms,
+                "aggregate_launches": t.aggregate_launches}
+
+
+# ---- module-level functions with the reference's names, bound to a lazily created default context ----
+_default = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device_id=None):
+    if device_id is None:
+        device_id = int(os.environ.get("ASW_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _default_lock:
+        if device_id not in _default:
+            _default[device_id] = Context(device_id)
+        return _default[device_id]
+
+
+def _bind(name):
+    def f(*args, **kwargs):
+        return getattr(default_context(), name)(*args, **kwargs)
+    f.__name__ = name
+    f.__doc__ = getattr(Context, name).__doc__
+    return f
+
+
+stereoMatching = _bind("stereoMatching")
+computeAD = _bind("computeAD")
+computeTAD = _bind("computeTAD")
+computeSimilarity = _bind("computeSimilarity")
+getCostSAD = _bind("getCostSAD")
+computeAdaptiveWeight = _bind("computeAdaptiveWeight")
+computeAdaptiveWeight_geodesic = _bind("computeAdaptiveWeight_geodesic")
+getGeodesicDist = _bind("getGeodesicDist")
+getGuidedFilter = _bind("getGuidedFilter")
+computeAdaptiveWeight_GuidedF = _bind("computeAdaptiveWeight_GuidedF")
+computeAdaptiveWeight_GuidedF_2 = _bind("computeAdaptiveWeight_GuidedF_2")
+computeAdaptiveWeight_WeightedMedian = _bind("computeAdaptiveWeight_WeightedMedian")
+winnerTakeAll = _bind("winnerTakeAll")

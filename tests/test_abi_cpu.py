@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/asw_mi355x.h declares; enum values equal the reference's.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import aswstereomatch_amd as asw
+from aswstereomatch_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so():
+    build.build()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_symbols_are_exported(so):
+    hdr = open(os.path.join(ROOT, "include", "asw_mi355x.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(asw_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(so, name), name
+
+
+def test_enum_values_match_reference():
+    # parametersStereo.h:4-24
+    A = asw.StereoMatchingAlgorithms
+    assert [int(A.BM), int(A.SGBM), int(A.ADAPTIVE_WEIGHT), int(A.ADAPTIVE_WEIGHT_8DIRECT), int(A.ADAPTIVE_WEIGHT_GEODESIC),
+            int(A.ADAPTIVE_WEIGHT_BILATERAL_GRID), int(A.ADAPTIVE_WEIGHT_BLO1), int(A.ADAPTIVE_WEIGHT_GUIDED_FILTER),
+            int(A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2), int(A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3), int(A.ADAPTIVE_WEIGHT_MEDIAN),
+            int(A.NCC)] == list(range(12))
+    assert int(asw.DISPARITY_LEFT) == 0 and int(asw.DISPARITY_RIGHT) == 1
+    hdr = open(os.path.join(ROOT, "include", "asw_mi355x.h")).read()
+    for name, val in [("ASW_ALG_ADAPTIVE_WEIGHT", 2), ("ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC", 4),
+                      ("ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER", 7), ("ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2", 8),
+                      ("ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN", 10), ("ASW_ALG_NCC", 11)]:
+        assert re.search(r"%s\s*=\s*%d\b" % (name, val), hdr), name
+
+
+def test_status_strings(so):
+    so.asw_status_string.restype = ctypes.c_char_p
+    assert so.asw_status_string(0) == b"ok"
+    assert b"odd" in so.asw_status_string(2)
+
+
+def test_product_does_not_import_oracle():
+    # the product package must never route through the CPU oracle
+    pkg = os.path.join(ROOT, "aswstereomatch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "asw_oracle" not in src, f
+                assert "from oracle" not in src and "import oracle" not in src, f

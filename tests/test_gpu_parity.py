@@ -1,0 +1,116 @@
+"""GPU parity tests: every HIP path, called through the C-ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  Integer / index outputs bit-exact; float cost volumes within rtol 1e-4
+(BASELINE.json north_star).  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import aswstereomatch_amd as asw
+from aswstereomatch_amd.synth import make_pair, shifted_pair
+
+pytestmark = pytest.mark.gpu
+
+A = asw.StereoMatchingAlgorithms
+LEFT, RIGHT = asw.DISPARITY_LEFT, asw.DISPARITY_RIGHT
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = asw.Context(0)
+    yield c
+    c.close()
+
+
+def _close(a, b, rtol=1e-4):
+    return np.allclose(a, b, rtol=rtol, atol=1e-30)
+
+
+# ---------------------------------------------------------------- streaming kernels
+@pytest.mark.parametrize("shape", [(7, 13), (37, 64), (288, 384)])
+def test_bgr2gray(ctx, oracle, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape + (3,)).astype(np.uint8)
+    assert np.array_equal(ctx.bgr2gray(img), oracle.bgr2gray(img))
+
+
+@pytest.mark.parametrize("H,W,C,dt,minD,numD", [
+    (9, 21, 3, 0, 0, 5), (9, 21, 3, 1, 0, 5), (16, 64, 1, 0, 0, 9), (16, 64, 1, 1, 2, 7),
+    (33, 100, 3, 0, 3, 40), (5, 8, 3, 0, 0, 30),  # disparity range larger than the width: repeated reflection
+    (288, 384, 3, 0, 0, 16)])
+def test_cost_ad_tad(ctx, oracle, H, W, C, dt, minD, numD):
+    rng = np.random.default_rng(H * W + C)
+    shp = (H, W, 3) if C == 3 else (H, W)
+    L = rng.integers(0, 256, shp).astype(np.uint8)
+    R = rng.integers(0, 256, shp).astype(np.uint8)
+    rc, want = oracle.compute_ad(L, R, dt, minD, numD)
+    got = ctx.computeAD(L, R, dt, minD, numD)
+    assert rc == 0 and len(got) == numD and np.array_equal(np.stack(got), want)
+    rc, want = oracle.compute_tad(L, R, dt, 30, minD, numD)
+    got = ctx.computeTAD(L, R, dt, 30, minD, numD)
+    assert np.array_equal(np.stack(got), want) and set(np.unique(np.stack(got))) <= {0, 255}
+
+
+def test_cost_ad_reference_error_behaviour(ctx):
+    L = np.zeros((8, 8, 3), np.uint8)
+    assert ctx.computeAD(L, np.zeros((8, 9, 3), np.uint8)) == [] and asw.last_status() == asw.ERR_SIZE_MISMATCH
+
+
+@pytest.mark.parametrize("n,H,W,minD", [(5, 7, 9, 0), (17, 36, 64, 3), (64, 100, 128, 0)])
+def test_wta(ctx, oracle, n, H, W, minD):
+    rng = np.random.default_rng(n)
+    vol = rng.random((n, H, W), dtype=np.float32)
+    vol[:, 0, 0] = np.nan            # all-NaN column -> 0
+    vol[:, 1, 1] = 0.5               # ties -> lowest d
+    vol[0, 2, 2] = np.inf
+    vol[:, 3, 3] = np.inf            # (double)inf < DBL_MAX is false -> never selected -> 0
+    vol[1:, 4, 4] = -np.inf
+    assert np.array_equal(ctx.winnerTakeAll(vol, minD), oracle.wta(vol, minD))
+
+
+# ---------------------------------------------------------------- classic bilateral ASW
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [
+    (24, 40, 5, 0, 8, 3),       # smaller than one tile
+    (37, 130, 7, 0, 20, 4),     # ragged tile edges, two d-chunks
+    (20, 70, 15, 2, 33, 5),     # reference window, minDisparity != 0, three d-chunks
+    (12, 64, 3, 0, 80, 6),      # disparity range larger than the width (max(0,x-d) clamps)
+    (64, 96, 35, 0, 16, 7),     # Cones-config window (DC=8 variant)
+])
+def test_classic_bilateral_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_classic(L, R, 30, 20, 0, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD + 1, H, W)
+    assert np.array_equal(v_got, v_want)   # same summation order -> E bit-identical (not just 1e-4)
+    assert np.array_equal(d_got, d_want)   # WTA index bit-exact
+    assert _close(v_got, v_want)
+
+
+def test_classic_selector_and_shift(ctx, oracle):
+    d0 = 5
+    L, R = shifted_pair(40, 64, d0)
+    d = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8)
+    assert (d[8:-8, 16:-8] == d0).all()
+    rc, want = oracle.stereo_matching(L, R, 0, 2, 7, 0, 8)
+    assert np.array_equal(d, want)
+    # inclusive range: numDisparity = d0 still finds d0 (K7)
+    d = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 7, 0, d0)
+    assert (d[8:-8, 16:-8] == d0).all()
+
+
+def test_classic_tsukuba_shape_config1(ctx, oracle):
+    # BASELINE.json configs[0]: 384x288, D=16, win 15
+    L, R, _ = make_pair(288, 384, 16, seed=1234)
+    rc, want = oracle.stereo_matching(L, R, 0, 2, 15, 0, 16)
+    got = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 15, 0, 16)
+    assert rc == 0 and np.array_equal(got, want)
+
+
+def test_error_behaviour(ctx):
+    L, R, _ = make_pair(16, 32, 4, seed=1)
+    assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
+    assert ctx.stereoMatching(L, R[:, :30], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) is None
+    assert asw.last_status() == asw.ERR_SIZE_MISMATCH
+    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, A.ADAPTIVE_WEIGHT_BLO1,
+                A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.NCC):
+        with pytest.raises(asw.AswError) as e:
+            ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
+        assert e.value.status == asw.ERR_UNSUPPORTED_METHOD
