@@ -254,11 +254,12 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double
         }
     }
     std::vector<int4> taps(nt);
+    const int LW = bilateral_lds_row_stride(win);  // row stride of the kernel's LDS sample tile
     for (int i = 0; i < nt; i++) {
-        taps[i].x = dxs[i];
-        taps[i].y = dys[i];
-        taps[i].z = (dxw[i] + 128) | ((dyw[i] + 128) << 16);
-        taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]];
+        taps[i].x = dys[i] * LW + dxs[i];  // sample cell, consume order (transposed, App. B-2)
+        taps[i].y = dxw[i];                // weight direction, build order
+        taps[i].z = dyw[i];
+        taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256;
     }
     ASW_TRY(t.taps.ensure(taps.size() * sizeof(int4)));
     ASW_TRY(t.lut.ensure(lut.size() * sizeof(float)));

@@ -68,10 +68,11 @@ struct BilateralLaunch {
     const uint8_t* gL;
     const uint8_t* gR;
     int H, W, win, minD, nD;  // nD = number of candidates (numD + 1 for the reference's inclusive range)
-    const int4* taps;         // {sample dx, sample dy, weight dx | weight dy<<16 (biased), class}
+    const int4* taps;         // {sample cell offset dys*LW+dxs, weight dx, weight dy, class*256}
     const float* lut;         // [ncls][256]
     int ntaps;
     float* vol;  // optional [nD][H][W]
     float* disp; // [H][W]
 };
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
+int bilateral_lds_row_stride(int win);  // LW of the kernel's sample tile (taps[].x is expressed in it)

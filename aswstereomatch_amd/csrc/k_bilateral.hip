@@ -15,9 +15,12 @@
 //    every d still sees its additions in ascending tap order, so E is bit-identical to the
 //    reference order (only the order WITHIN one d matters for rounding);
 //  * ab*cost is exact in f64 (24-bit x 8-bit significands), so fma(ab, cost, num) == num + ab*cost;
-//  * per d-chunk the gray abs-diff cost C[ny][nx][d] is built once in LDS (16 B per cell, one
-//    ds_read_b128 per tap), and per tap-group the left/right weights of the tile rows are staged in
-//    LDS so that the inner loop is LDS reads + VALU only;
+//  * per d-chunk the gray abs-diff cost C[ny][nx][d] is built once in LDS (DC bytes per cell, one
+//    ds_read_b128 per tap at DC=16); per tap-group the right-image weights of the tile rows are
+//    staged in LDS (each is shared by up to DC (pixel,d) pairs), the left-image weight belongs to
+//    exactly one thread and is looked up inline;
+//  * the candidate count (numD+1 = 129 at D=128) is covered by 16-wide chunks plus 8/4/2/1-wide
+//    remainder chunks, so no lane computes a disparity that is thrown away;
 //  * clamp borders are reproduced by building the tiles with clamped coordinates (M.cpp:1059-1060,
 //    1101-1106); the right-hand weight is evaluated AT max(0,x-d) (its neighbour is clamped from
 //    there), which is why the right staging clamps explicitly.
@@ -26,197 +29,239 @@
 
 namespace {
 
-constexpr int TW = 64;  // tile width  = one wavefront
-constexpr int TH = 4;   // tile height = waves per workgroup
+constexpr int TW = 64;     // tile width  = one wavefront
+constexpr int TH = 4;      // tile height = waves per workgroup
+constexpr int DCMAX = 16;  // widest d-chunk
 
 struct BilParams {
-    const uint8_t* gL;
-    const uint8_t* gR;
-    const int4* taps;
-    const float* lut;
-    float* vol;
-    float* disp;
     int H, W, h, minD, nD, ntaps;
-    // LDS layout (bytes from the start of dynamic LDS)
-    int LW, LWp, RW, RWp, TR;
-    int offL, offR, offC, offWR, offWL;
 };
 
-template <int DC, int G>
-__global__ __launch_bounds__(256, 2) void k_asw_bilateral(BilParams p)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint8_t* sL = smem + p.offL;
-    uint8_t* sR = smem + p.offR;
-    uint8_t* sC = smem + p.offC;
-    float* sWR = reinterpret_cast<float*>(smem + p.offWR);
-    float* sWL = reinterpret_cast<float*>(smem + p.offWL);
-    constexpr int SWR = TW + DC - 1;
+constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// LDS layout as a function of the half window h (compile-time when HH > 0)
+struct Layout {
+    int h, TR, LW, LWp, RW, RWp, offC, offWR, offL, offR, total;
+    __host__ __device__ constexpr Layout(int h_, int G)
+        : h(h_), TR(TH + 2 * h_), LW(TW + 2 * h_), LWp(round_up(TW + 2 * h_, 4)), RW(TW + 2 * h_ + DCMAX - 1),
+          RWp(round_up(TW + 2 * h_ + DCMAX - 1, 4)), offC(0), offWR(round_up((TH + 2 * h_) * (TW + 2 * h_) * DCMAX, 16)),
+          offL(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16)),
+          offR(offL + round_up((TH + 2 * h_) * round_up(TW + 2 * h_, 4), 16)),
+          total(offR + round_up((TH + 2 * h_) * round_up(TW + 2 * h_ + DCMAX - 1, 4), 16))
+    {
+    }
+};
+
+template <int DC>
+__device__ __forceinline__ void load_cost(const uint8_t* cell, uint32_t (&cw)[(DC + 3) / 4])
+{
+    if constexpr (DC == 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(cell);
+        cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+    } else if constexpr (DC == 8) {
+        uint2 v = *reinterpret_cast<const uint2*>(cell);
+        cw[0] = v.x; cw[1] = v.y;
+    } else if constexpr (DC == 4) {
+        cw[0] = *reinterpret_cast<const uint32_t*>(cell);
+    } else if constexpr (DC == 2) {
+        cw[0] = *reinterpret_cast<const uint16_t*>(cell);
+    } else {
+        cw[0] = cell[0];
+    }
+}
+
+// One chunk of DC consecutive disparities starting at d0 (candidate index c0) for the whole tile.
+// G = 8 taps per group; win*win-1 = (win-1)(win+1) is a multiple of 8 for every odd win, so groups
+// are always full.
+template <int DC, int G>
+__device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t* __restrict__ gR,
+                                              const int4* __restrict__ taps, const float* __restrict__ lut,
+                                              float* __restrict__ vol, const Layout& lay, unsigned char* smem, int c0,
+                                              double& bestE, float& bestD)
+{
+    uint8_t* sL = smem + lay.offL;
+    uint8_t* sR = smem + lay.offR;
+    uint8_t* sC = smem + lay.offC;
+    float* sWR = reinterpret_cast<float*>(smem + lay.offWR);
+    constexpr int SWR = TW + DC - 1;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int H = p.H, W = p.W, h = p.h, LW = p.LW, LWp = p.LWp, RW = p.RW, RWp = p.RWp, TR = p.TR;
+    const int H = p.H, W = p.W, h = lay.h, LW = lay.LW, LWp = lay.LWp, RWp = lay.RWp, TR = lay.TR;
+    const int RW = TW + 2 * h + DC - 1;
+    const int d0 = p.minD + c0;
+    // first image column of the right tile.  Never left of -h: once max(0,x-d) clamps to column 0 the
+    // tile must still hold columns 0..h (the clamped pixel's neighbours).
+    const int sRx0 = max(x0 - h - (d0 + DC - 1), -h);
 
-    // left gray tile with replicate-clamped coordinates, staged once
+    __syncthreads();  // previous chunk finished reading sR / sC / sWR
+    for (int i = tid; i < TR * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
+        sR[r * RWp + c] = gR[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+    // cost tile: C[r][c][dd] = |gL(ny,nx) - gR(ny, max(0, nx-d))|   (M.cpp:1106)
     for (int i = tid; i < TR * LW; i += 256) {
         int r = i / LW, c = i - r * LW;
+        int nx = min(max(x0 - h + c, 0), W - 1);
+        int gl = sL[r * LWp + c];
+        uint32_t pk[(DC + 3) / 4];
+#pragma unroll
+        for (int q = 0; q < (DC + 3) / 4; q++) pk[q] = 0;
+#pragma unroll
+        for (int dd = 0; dd < DC; dd++) {
+            int xr = max(0, nx - (d0 + dd));
+            int v = abs(gl - (int)sR[r * RWp + min(xr - sRx0, RW - 1)]);
+            pk[dd >> 2] |= (uint32_t)v << (8 * (dd & 3));
+        }
+        if constexpr (DC >= 4) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sC + (size_t)i * DC);
+#pragma unroll
+            for (int q = 0; q < DC / 4; q++) dst[q] = pk[q];
+        } else {
+#pragma unroll
+            for (int dd = 0; dd < DC; dd++) sC[(size_t)i * DC + dd] = (uint8_t)(pk[0] >> (8 * dd));
+        }
+    }
+
+    double num[DC], den[DC];
+#pragma unroll
+    for (int dd = 0; dd < DC; dd++) { num[dd] = 0.0; den[dd] = 0.0; }
+
+    const uint8_t* myL = sL + (ty + h) * LWp + (tx + h);     // this thread's own left pixel
+    const int ctrL = *myL;
+    const uint8_t* myC = sC + (size_t)((ty + h) * LW + (tx + h)) * DC;
+    const float* myWR = sWR + ty * SWR + tx + (DC - 1);
+
+    // right-weight staging positions: pass A = (row ty, j = tx); pass B (wave 0 only) = the DC-1 extra
+    // columns of all four rows.  xr = clamp(x0 - d0 - (DC-1) + j): the right pixel a weight is evaluated AT.
+    // Neighbour columns are clamped in tile coordinates: image column X sits at tile column X - sRx0.
+    const int colLo = max(-sRx0, 0), colHi = min(W - 1 - sRx0, RW - 1);
+    const int colA = min(max(x0 - d0 - (DC - 1) + tx, 0), W - 1) - sRx0;
+    const uint8_t* rowA = sR + (ty + h) * RWp;
+    const int ctrA = rowA[min(colA, RW - 1)];
+    constexpr int NEXTRA = TH * (DC - 1);
+    const int rowBi = (DC > 1) ? min(tx / (DC > 1 ? DC - 1 : 1), TH - 1) : 0;
+    const int jB = TW + tx - rowBi * (DC - 1);
+    const int colB = min(max(x0 - d0 - (DC - 1) + jB, 0), W - 1) - sRx0;
+    const uint8_t* rowB = sR + (rowBi + h) * RWp;
+    const int ctrB = rowB[min(colB, RW - 1)];
+    float* dstA = sWR + ty * SWR + tx;
+    float* dstB = sWR + rowBi * SWR + jB;
+
+    for (int g0 = 0; g0 < p.ntaps; g0 += G) {
+        __syncthreads();  // previous group's weights consumed (first pass: cost tile complete)
+        float wlv[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const int4 tp = taps[g0 + t];  // uniform: scalar loads
+            // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
+            {
+                int nc = min(max(colA + tp.y, colLo), colHi);
+                int nb = rowA[tp.z * RWp + nc];
+                dstA[t * (TH * SWR)] = lut[__builtin_amdgcn_sad_u16(nb, ctrA, tp.w)];
+            }
+            if (DC > 1 && ty == 0) {
+                if (tx < NEXTRA) {
+                    int nc = min(max(colB + tp.y, colLo), colHi);
+                    int nb = rowB[tp.z * RWp + nc];
+                    dstB[t * (TH * SWR)] = lut[__builtin_amdgcn_sad_u16(nb, ctrB, tp.w)];
+                }
+            }
+            // this thread's own left-image weight (M.cpp:1062,1065)
+            wlv[t] = lut[__builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const int4 tp = taps[g0 + t];
+            const float wl = wlv[t];
+            uint32_t cw[(DC + 3) / 4];
+            load_cost<DC>(myC + tp.x * DC, cw);
+            const float* w = myWR + t * (TH * SWR);
+#pragma unroll
+            for (int dd = 0; dd < DC; dd++) {
+                float ab = wl * w[-dd];                             // f32 product, M.cpp:1104-1105
+                double abd = (double)ab;
+                double c = (double)(int)((cw[dd >> 2] >> (8 * (dd & 3))) & 0xffu);
+                num[dd] = __builtin_fma(abd, c, num[dd]);           // exact product -> == num + ab*c
+                den[dd] = den[dd] + abd;                            // M.cpp:1107-1108
+            }
+        }
+    }
+
+    const int x = x0 + tx, y = y0 + ty;
+    if (x < W && y < H) {
+#pragma unroll
+        for (int dd = 0; dd < DC; dd++) {
+            double E = num[dd] / den[dd];  // M.cpp:1111
+            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + x] = (float)E;
+            if (E < bestE) {  // M.cpp:1145-1150, ascending d, strict <
+                bestE = E;
+                bestD = (float)(d0 + dd);
+            }
+        }
+    }
+}
+
+template <int HH, int G>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_asw_bilateral(
+    BilParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ taps,
+    const float* __restrict__ lut, float* __restrict__ vol, float* __restrict__ disp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Layout lay(HH > 0 ? HH : p.h, G);
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int H = p.H, W = p.W, h = lay.h;
+
+    // left gray tile with replicate-clamped coordinates, staged once
+    uint8_t* sL = smem + lay.offL;
+    for (int i = tid; i < lay.TR * lay.LW; i += 256) {
+        int r = i / lay.LW, c = i - r * lay.LW;
         int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(x0 - h + c, 0), W - 1);
-        sL[r * LWp + c] = p.gL[(size_t)yy * W + xx];
+        sL[r * lay.LWp + c] = gL[(size_t)yy * W + xx];
     }
 
     double bestE = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
     float bestD = 0.0f;
-    const int x = x0 + tx, y = y0 + ty;
+    int c0 = 0;
+    for (; c0 + 16 <= p.nD; c0 += 16) process_chunk<16, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD);
+    if (p.nD - c0 >= 8) { process_chunk<8, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 8; }
+    if (p.nD - c0 >= 4) { process_chunk<4, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 4; }
+    if (p.nD - c0 >= 2) { process_chunk<2, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 2; }
+    if (p.nD - c0 >= 1) { process_chunk<1, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 1; }
 
-    for (int c0 = 0; c0 < p.nD; c0 += DC) {
-        const int d0 = p.minD + c0;  // first disparity of the chunk
-        // first image column of the right tile.  Never left of -h: once max(0,x-d) clamps to column 0 the
-        // tile must still hold columns 0..h (the clamped pixel's neighbours).
-        const int sRx0 = max(x0 - h - (d0 + DC - 1), -h);
-        __syncthreads();  // previous chunk finished reading sR / sC
-        for (int i = tid; i < TR * RW; i += 256) {
-            int r = i / RW, c = i - r * RW;
-            int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
-            sR[r * RWp + c] = p.gR[(size_t)yy * W + xx];
-        }
-        __syncthreads();
-        // cost tile: C[r][c][dd] = |gL(ny,nx) - gR(ny, max(0, nx-d))|
-        for (int i = tid; i < TR * LW; i += 256) {
-            int r = i / LW, c = i - r * LW;
-            int nx = min(max(x0 - h + c, 0), W - 1);
-            int gl = sL[r * LWp + c];
-            uint32_t pk[(DC + 3) / 4];
-#pragma unroll
-            for (int q = 0; q < (DC + 3) / 4; q++) pk[q] = 0;
-#pragma unroll
-            for (int dd = 0; dd < DC; dd++) {
-                int xr = max(0, nx - (d0 + dd));
-                int v = abs(gl - (int)sR[r * RWp + min(xr - sRx0, RW - 1)]);  // tile is clamp-replicated
-                pk[dd >> 2] |= (uint32_t)v << (8 * (dd & 3));
-            }
-            uint32_t* dst = reinterpret_cast<uint32_t*>(sC + (size_t)i * DC);
-            if (DC >= 4) {
-#pragma unroll
-                for (int q = 0; q < DC / 4; q++) dst[q] = pk[q];
-            } else {
-#pragma unroll
-                for (int dd = 0; dd < DC; dd++) sC[(size_t)i * DC + dd] = (uint8_t)(pk[0] >> (8 * dd));
-            }
-        }
-
-        double num[DC], den[DC];
-#pragma unroll
-        for (int dd = 0; dd < DC; dd++) { num[dd] = 0.0; den[dd] = 0.0; }
-
-        for (int g0 = 0; g0 < p.ntaps; g0 += G) {
-            const int ng = min(G, p.ntaps - g0);
-            __syncthreads();  // previous group's weights consumed (first pass: cost tile complete)
-            // right-image weights for xr = clamp(x0 - d0 - (DC-1) + j), j in [0, SWR)
-            for (int i = tid; i < ng * TH * SWR; i += 256) {
-                int tt = i / (TH * SWR), rem = i - tt * (TH * SWR);
-                int row = rem / SWR, j = rem - row * SWR;
-                int4 tp = p.taps[g0 + tt];
-                int dxw = (tp.z & 0xffff) - 128, dyw = (tp.z >> 16) - 128;
-                int xr = min(max(x0 - d0 - (DC - 1) + j, 0), W - 1);
-                int xn = min(max(xr + dxw, 0), W - 1);
-                // the tile is clamp-replicated, so a column left/right of it holds the same value as its edge
-                int ctr = sR[(row + h) * RWp + min(xr - sRx0, RW - 1)];
-                int nb = sR[(row + h + dyw) * RWp + min(xn - sRx0, RW - 1)];
-                sWR[i] = p.lut[tp.w * 256 + abs(nb - ctr)];
-            }
-            // left-image weights at the tile's own pixels
-            for (int i = tid; i < ng * TH * TW; i += 256) {
-                int tt = i / (TH * TW), rem = i - tt * (TH * TW);
-                int row = rem / TW, c = rem - row * TW;
-                int4 tp = p.taps[g0 + tt];
-                int dxw = (tp.z & 0xffff) - 128, dyw = (tp.z >> 16) - 128;
-                int ctr = sL[(row + h) * LWp + (c + h)];
-                int nb = sL[(row + h + dyw) * LWp + (c + h + dxw)];
-                sWL[i] = p.lut[tp.w * 256 + abs(nb - ctr)];
-            }
-            __syncthreads();
-            for (int tt = 0; tt < ng; tt++) {
-                const int4 tp = p.taps[g0 + tt];  // uniform -> scalar loads
-                const float wl = sWL[(tt * TH + ty) * TW + tx];
-                const uint8_t* cell = sC + (size_t)((ty + h + tp.y) * LW + (tx + h + tp.x)) * DC;
-                const float* wr = sWR + (tt * TH + ty) * SWR + tx + (DC - 1);
-                uint32_t cw[(DC + 3) / 4];
-                if (DC == 16) {
-                    uint4 v = *reinterpret_cast<const uint4*>(cell);
-                    cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-                } else if (DC == 8) {
-                    uint2 v = *reinterpret_cast<const uint2*>(cell);
-                    cw[0] = v.x; cw[1] = v.y;
-                } else if (DC == 4) {
-                    cw[0] = *reinterpret_cast<const uint32_t*>(cell);
-                } else {
-                    cw[0] = 0;
-#pragma unroll
-                    for (int dd = 0; dd < DC; dd++) cw[0] |= (uint32_t)cell[dd] << (8 * dd);
-                }
-#pragma unroll
-                for (int dd = 0; dd < DC; dd++) {
-                    float ab = wl * wr[-dd];                        // f32 product, M.cpp:1104-1105
-                    double abd = (double)ab;
-                    double c = (double)(int)((cw[dd >> 2] >> (8 * (dd & 3))) & 0xffu);
-                    num[dd] = __builtin_fma(abd, c, num[dd]);       // exact product -> == num + ab*c
-                    den[dd] = den[dd] + abd;                        // M.cpp:1107-1108
-                }
-            }
-        }
-
-        if (x < W && y < H) {
-#pragma unroll
-            for (int dd = 0; dd < DC; dd++) {
-                if (c0 + dd < p.nD) {
-                    double E = num[dd] / den[dd];  // M.cpp:1111
-                    if (p.vol) p.vol[((size_t)(c0 + dd) * H + y) * W + x] = (float)E;
-                    if (E < bestE) {  // M.cpp:1145-1150, ascending d, strict <
-                        bestE = E;
-                        bestD = (float)(d0 + dd);
-                    }
-                }
-            }
-        }
-    }
-    if (x < W && y < H) p.disp[(size_t)y * W + x] = bestD;
+    const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
+    if (x < W && y < H) disp[(size_t)y * W + x] = bestD;
 }
 
-inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
-
-template <int DC, int G>
+template <int HH, int G>
 int launch_t(hipStream_t s, const BilateralLaunch& a)
 {
     BilParams p;
-    p.gL = a.gL; p.gR = a.gR; p.taps = a.taps; p.lut = a.lut; p.vol = a.vol; p.disp = a.disp;
     p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps;
-    const int h = p.h;
-    p.TR = TH + 2 * h;
-    p.LW = TW + 2 * h;
-    p.LWp = round_up(p.LW, 4);
-    p.RW = TW + 2 * h + DC - 1;
-    p.RWp = round_up(p.RW, 4);
-    int off = 0;
-    p.offC = off; off += round_up(p.TR * p.LW * DC, 16);
-    p.offWR = off; off += round_up(G * TH * (TW + DC - 1) * 4, 16);
-    p.offWL = off; off += G * TH * TW * 4;
-    p.offL = off; off += round_up(p.TR * p.LWp, 16);
-    p.offR = off; off += round_up(p.TR * p.RWp, 16);
-    if (off > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
-    auto kern = k_asw_bilateral<DC, G>;
-    if (off > 64 * 1024) ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+    const Layout lay(p.h, G);
+    if (lay.total > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
+    auto kern = k_asw_bilateral<HH, G>;
+    if (lay.total > 64 * 1024)
+        ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total));
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, grid, dim3(256), off, s, p);
+    if (a.ntaps % G != 0) return ASW_ERR_BAD_ARGUMENT;  // cannot happen for odd windows
+    hipLaunchKernelGGL(kern, grid, dim3(256), lay.total, s, p, a.gL, a.gR, a.taps, a.lut, a.vol, a.disp);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
 
 }  // namespace
 
+int bilateral_lds_row_stride(int win) { return TW + 2 * (win / 2); }
+
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a)
 {
-    // large windows: the cost tile grows with (64+2h)*(4+2h)*DC, keep it inside LDS
-    if (a.win <= 21) return launch_t<16, 8>(s, a);
-    if (a.win <= 45) return launch_t<8, 8>(s, a);
-    return launch_t<4, 4>(s, a);
+    switch (a.win) {
+    case 15: return launch_t<7, 8>(s, a);   // the reference's call site (main.cpp:94) and configs C1/C5
+    case 35: return launch_t<17, 8>(s, a);  // config C2
+    default: return launch_t<0, 8>(s, a);   // any other odd window: layout computed at run time
+    }
 }
