@@ -310,6 +310,88 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     return ASW_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// guided-filter ASW: computeAdaptiveWeight_GuidedF_2 (M.cpp:2976-3050, TAD C+G cost, guide = left image)
+// and computeAdaptiveWeight_GuidedF (M.cpp:2867-2963, SAD cost, 6-channel guide [L, R shifted by d])
+// ------------------------------------------------------------------------------------------
+static int build_similarity_volume(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int W, int minD, int numD,
+                                   double regularity, double thresC, double thresG, float* cost)
+{
+    const int max_off = minD + numD - 1;
+    DevBuf& gl = ctx->buf("scharrL");
+    DevBuf& gr = ctx->buf("scharrR");
+    ASW_TRY(gl.ensure((size_t)H * W * 3 * sizeof(short)));
+    ASW_TRY(gr.ensure((size_t)H * (W + max_off) * 3 * sizeof(short)));
+    ASW_TRY(launch_scharr_x(ctx->stream, dL, H, W, 0, gl.as<short>()));
+    ASW_TRY(launch_scharr_x(ctx->stream, dR, H, W, max_off, gr.as<short>()));  // gradient of the PADDED right image
+    return launch_similarity(ctx->stream, dL, dR, gl.as<short>(), gr.as<short>(), H, W, minD, numD, regularity, thresC, thresG,
+                             cost);
+}
+
+static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume, bool variant2)
+{
+    if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    // GuidedF_2: RIGHT / gray branches of computeSimilarity throw in the reference (App. B-7).
+    // GuidedF RIGHT exists in the reference; it is a "next" row here.
+    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (!variant2 && mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // getCostSAD_d, M.cpp:2458-2462
+    if (mp.win < 1 || mp.win > 128) return ASW_ERR_BAD_ARGUMENT;
+    const int H = f->rows, W = f->cols, n = mp.numD, C = variant2 ? 3 : 6;
+    const size_t plane = (size_t)H * W;
+    DevBuf& raw = ctx->buf("g_raw");
+    DevBuf& ord = ctx->buf("g_ord");
+    DevBuf& psc = ctx->buf("g_pscales");
+    DevBuf& gsc = ctx->buf("g_gscales");
+    DevBuf& meanI = ctx->buf("g_meanI");
+    DevBuf& den = ctx->buf("g_den");
+    DevBuf& ab = ctx->buf("g_ab");
+    const int nstat = variant2 ? 1 : n;
+    ASW_TRY(raw.ensure(plane * n * 4));
+    ASW_TRY(ord.ensure((size_t)(2 * n + 2) * 4));
+    ASW_TRY(psc.ensure((size_t)n * sizeof(float2)));
+    ASW_TRY(gsc.ensure((size_t)n * sizeof(float2)));
+    ASW_TRY(meanI.ensure(plane * C * nstat * 4));
+    ASW_TRY(den.ensure(plane * C * nstat * 4));
+    ASW_TRY(ab.ensure(plane * (C + 1) * n * 4));
+    ASW_TRY(f->vol.ensure(plane * n * 4));  // q volume: always needed for the WTA pass
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = keep_volume ? plane * n : 0;
+    const uint8_t* dL = f->L.as<uint8_t>();
+    const uint8_t* dR = f->R.as<uint8_t>();
+
+    GuidedLaunch a;
+    a.mode = variant2 ? 0 : 1; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
+    a.guideA = dL; a.guideB = dR;
+    if (variant2) {
+        ASW_TRY(build_similarity_volume(ctx, dL, dR, H, W, mp.minD, n, 0.4, 10, 50, raw.as<float>()));  // M.cpp:2990
+        ASW_TRY(launch_u8_scale(ctx->stream, dL, plane * 3, ord.as<uint32_t>() + 2 * n, gsc.as<float2>()));
+    } else {
+        DevBuf& gl = ctx->buf("grayL");
+        DevBuf& gr = ctx->buf("grayR");
+        DevBuf& colmm = ctx->buf("g_colmm");
+        ASW_TRY(gl.ensure(plane));
+        ASW_TRY(gr.ensure(plane));
+        ASW_TRY(colmm.ensure((size_t)2 * W * sizeof(int)));
+        ASW_TRY(launch_bgr2gray(ctx->stream, dL, H, W, gl.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, dR, H, W, gr.as<uint8_t>()));
+        ASW_TRY(launch_cost_sad(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, n,
+                                raw.as<float>()));  // M.cpp:2884-2889
+        ASW_TRY(launch_guide_scales_lr(ctx->stream, dL, dR, H, W, mp.minD, n, mp.disparity_type, ord.as<uint32_t>() + 2 * n,
+                                       colmm.as<int>(), gsc.as<float2>()));
+    }
+    ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));  // M.cpp:2775
+    a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
+    a.H = H; a.W = W; a.n = n; a.r = mp.win; a.minD = mp.minD; a.eps = mp.eps;
+    a.meanI = meanI.as<float>(); a.den = den.as<float>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ASW_TRY(launch_guided(ctx->stream, a));
+    ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->timing.aggregate_launches = variant2 ? 4 : 5;
+    return ASW_OK;
+}
+
 static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume)
 {
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
@@ -318,6 +400,8 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     int rc;
     switch (algorithm) {  // M.cpp:49-87
     case ASW_ALG_ADAPTIVE_WEIGHT: rc = run_bilateral(ctx, f, mp, keep_volume); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, false); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, true); break;
     default: rc = ASW_ERR_UNSUPPORTED_METHOD; break;
     }
     if (rc != ASW_OK) return rc;
@@ -449,16 +533,138 @@ extern "C" int asw_wta(asw_ctx* ctx, const float* cost_volume, int n, int rows, 
     return ASW_OK;
 }
 
+
+extern "C" int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                    int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
+                                    float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER, mp, cost_volume_out);
+}
+
+extern "C" int asw_aggregate_guided2(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                     int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
+                                     float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2, mp, cost_volume_out);
+}
+
+extern "C" int asw_cost_similarity(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost,
+                                   double regularity, double thres_c, double thres_g, int disparity_type, int win_size,
+                                   int min_disparity, int num_disparity)
+{
+    if (!ctx || !cost) return ASW_ERR_BAD_ARGUMENT;
+    if (win_size != 0 && win_size % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:654-657 (before anything else)
+    ASW_TRY(check_pair(left, right));
+    if (num_disparity <= 0 || min_disparity < 0 || win_size < 0) return ASW_ERR_BAD_ARGUMENT;
+    // only DISPARITY_LEFT + 3 channels executes in the reference; the other branches throw (App. B-7)
+    if (left->channels != 3 || disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const int H = left->rows, W = left->cols, n = num_disparity, h = win_size / 2;
+    DevBuf& dl = ctx->buf("stageL");
+    DevBuf& dr = ctx->buf("stageR");
+    DevBuf& raw = ctx->buf("g_raw");
+    ASW_TRY(upload_image(ctx, left, dl));
+    ASW_TRY(upload_image(ctx, right, dr));
+    ASW_TRY(raw.ensure((size_t)n * H * W * 4));
+    ASW_TRY(build_similarity_volume(ctx, dl.as<uint8_t>(), dr.as<uint8_t>(), H, W, min_disparity, n, regularity, thres_c, thres_g,
+                                    raw.as<float>()));
+    const float* src = raw.as<float>();
+    size_t out_floats = (size_t)n * H * W;
+    if (win_size > 0) {
+        DevBuf& pad = ctx->buf("g_pad");
+        out_floats = (size_t)n * (H + 2 * h) * (W + 2 * h);
+        ASW_TRY(pad.ensure(out_floats * 4));
+        ASW_TRY(launch_pad_reflect(ctx->stream, raw.as<float>(), n, H, W, h, pad.as<float>()));
+        src = pad.as<float>();
+    }
+    ASW_HIP_TRY(hipMemcpyAsync(cost, src, out_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
+extern "C" int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity_type,
+                            int win_size, int min_disparity, int num_disparity)
+{
+    if (!ctx || !cost) return ASW_ERR_BAD_ARGUMENT;
+    ASW_TRY(check_pair(left, right));
+    if (win_size % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:2458-2462
+    if (num_disparity <= 0 || min_disparity < 0 || win_size < 1 || win_size > 128) return ASW_ERR_BAD_ARGUMENT;
+    if (left->channels != 3 && left->channels != 1) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (disparity_type != ASW_DISPARITY_LEFT && disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const int H = left->rows, W = left->cols, n = num_disparity;
+    DevBuf& dl = ctx->buf("stageL");
+    DevBuf& dr = ctx->buf("stageR");
+    DevBuf& gl = ctx->buf("grayL");
+    DevBuf& gr = ctx->buf("grayR");
+    DevBuf& raw = ctx->buf("g_raw");
+    ASW_TRY(upload_image(ctx, left, dl));
+    ASW_TRY(upload_image(ctx, right, dr));
+    ASW_TRY(raw.ensure((size_t)n * H * W * 4));
+    const uint8_t *pl = dl.as<uint8_t>(), *pr = dr.as<uint8_t>();
+    if (left->channels == 3) {  // M.cpp:2446-2456
+        ASW_TRY(gl.ensure((size_t)H * W));
+        ASW_TRY(gr.ensure((size_t)H * W));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pl, H, W, gl.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pr, H, W, gr.as<uint8_t>()));
+        pl = gl.as<uint8_t>(); pr = gr.as<uint8_t>();
+    }
+    ASW_TRY(launch_cost_sad(ctx->stream, pl, pr, H, W, disparity_type, win_size, min_disparity, n, raw.as<float>()));
+    ASW_HIP_TRY(hipMemcpyAsync(cost, raw.p, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
+extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const float* p, float* q, int r, double eps)
+{
+    if (!ctx || !p || !q) return ASW_ERR_BAD_ARGUMENT;
+    ASW_TRY(check_u8_image(guide));
+    if (guide->channels != 3 && guide->channels != 6) return ASW_ERR_UNSUPPORTED_LAYOUT;  // M.cpp:2732-2734
+    if (r < 1 || r > 128) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const int H = guide->rows, W = guide->cols, C = guide->channels;
+    const size_t plane = (size_t)H * W;
+    DevBuf& dg = ctx->buf("stageL");
+    DevBuf& raw = ctx->buf("g_raw");
+    DevBuf& ord = ctx->buf("g_ord");
+    DevBuf& psc = ctx->buf("g_pscales");
+    DevBuf& gsc = ctx->buf("g_gscales");
+    DevBuf& meanI = ctx->buf("g_meanI");
+    DevBuf& den = ctx->buf("g_den");
+    DevBuf& ab = ctx->buf("g_ab");
+    DevBuf& qv = ctx->buf("g_q1");
+    ASW_TRY(upload_image(ctx, guide, dg));
+    ASW_TRY(raw.ensure(plane * 4));
+    ASW_TRY(ord.ensure(4 * 4));
+    ASW_TRY(psc.ensure(sizeof(float2)));
+    ASW_TRY(gsc.ensure(sizeof(float2)));
+    ASW_TRY(meanI.ensure(plane * C * 4));
+    ASW_TRY(den.ensure(plane * C * 4));
+    ASW_TRY(ab.ensure(plane * (C + 1) * 4));
+    ASW_TRY(qv.ensure(plane * 4));
+    ASW_HIP_TRY(hipMemcpyAsync(raw.p, p, plane * 4, hipMemcpyHostToDevice, ctx->stream));
+    ASW_TRY(launch_u8_scale(ctx->stream, dg.as<uint8_t>(), plane * C, ord.as<uint32_t>() + 2, gsc.as<float2>()));  // M.cpp:2774
+    ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), 1, plane, ord.as<uint32_t>(), psc.as<float2>()));     // M.cpp:2775
+    GuidedLaunch a;
+    a.mode = 2; a.C = C; a.guide_per_slice = 0; a.guideA = dg.as<uint8_t>(); a.guideB = nullptr;
+    a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
+    a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;
+    a.meanI = meanI.as<float>(); a.den = den.as<float>(); a.ab = ab.as<float>(); a.q = qv.as<float>();
+    ASW_TRY(launch_guided(ctx->stream, a));
+    ASW_HIP_TRY(hipMemcpyAsync(q, qv.p, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
 // ---- not built yet in this revision: report honestly instead of silently falling back ----
 #define ASW_TODO(name, ...) \
     extern "C" int name(__VA_ARGS__) { return ASW_ERR_UNSUPPORTED_METHOD; }
 
 ASW_TODO(asw_aggregate_geodesic, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, int, int, int, float*)
-ASW_TODO(asw_aggregate_guided, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, double, int, int, int, float*)
-ASW_TODO(asw_aggregate_guided2, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, double, int, int, int, float*)
 ASW_TODO(asw_aggregate_wmedian, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, int, double, double, int, int, float*)
-ASW_TODO(asw_cost_similarity, asw_ctx*, const asw_image*, const asw_image*, float*, double, double, double, int, int, int, int)
-ASW_TODO(asw_cost_sad, asw_ctx*, const asw_image*, const asw_image*, float*, int, int, int, int)
-ASW_TODO(asw_guided_filter, asw_ctx*, const asw_image*, const float*, float*, int, double)
 ASW_TODO(asw_geodesic_dist, asw_ctx*, const asw_image*, float*, int, int)
 ASW_TODO(asw_stereo_match_batch, int, const asw_image*, const asw_image*, asw_image*, int, int, int, int, int, int, const int*)

@@ -76,3 +76,35 @@ struct BilateralLaunch {
 };
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 int bilateral_lds_row_stride(int win);  // LW of the kernel's sample tile (taps[].x is expressed in it)
+
+// ---- cost kernels (k_cost.hip) ----
+int launch_scharr_x(hipStream_t s, const uint8_t* img, int H, int W, int pad, short* grad /* [H][W+pad][3] */);
+int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const short* gL, const short* gR, int H, int W,
+                      int minD, int numD, double regularity, double thresC, double thresG, float* cost);
+int launch_pad_reflect(hipStream_t s, const float* src, int n, int H, int W, int h, float* dst);
+// per-slice normalize(NORM_MINMAX) parameters {scale, shift} of a dense f32 volume [n][plane]
+int launch_slice_scales(hipStream_t s, const float* vol, int n, size_t plane, uint32_t* ord_scratch /* 2n */, float2* scales);
+int launch_u8_scale(hipStream_t s, const uint8_t* img, size_t nbytes, uint32_t* ord_scratch /* 2 */, float2* scale1);
+int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t* shifted_img, int H, int W, int minD, int numD,
+                           int disp_type, uint32_t* ord_scratch, int* colmm_scratch /* 2W */, float2* scales /* numD */);
+
+// ---- box means / guided filter (k_guided.hip) ----
+int launch_box_filter(hipStream_t s, const float* in, float* out, int n, int H, int W, int k);
+int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
+                    int numD, float* cost);
+struct GuidedLaunch {
+    const uint8_t* guideA;  // mode 0/1: 3-channel reference image; mode 2: C-channel interleaved guide
+    const uint8_t* guideB;  // mode 1: the image whose disparity-shifted view forms channels 3..5
+    int mode, C;            // C = 3 or 6
+    int guide_per_slice;    // 1: guide (hence its statistics and scales) changes with the slice
+    const float2* gscales;  // guide normalize() parameters (1 or n entries)
+    const float* P;         // raw cost volume [n][H][W]
+    const float2* pscales;  // per-slice normalize() parameters of P
+    int H, W, n, r, minD;
+    double eps;
+    float* meanI;           // scratch [nstat][C][H][W]
+    float* den;             // scratch [nstat][C][H][W]
+    float* ab;              // scratch [n][C+1][H][W]
+    float* q;               // out [n][H][W]
+};
+int launch_guided(hipStream_t s, const GuidedLaunch& a);

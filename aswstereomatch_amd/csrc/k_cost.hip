@@ -1,0 +1,277 @@
+// Cost-volume kernels of the guided-filter / weighted-median paths:
+//   Scharr-x gradients (filter2D, M.cpp:446-450), TAD C+G similarity (computeSimilarity, M.cpp:415-487),
+//   REFLECT padding of the planes (M.cpp:651-668), per-slice min/max (normalize NORM_MINMAX, M.cpp:2774-2775).
+// All arithmetic follows the MatExpr evaluation order of M.cpp:455-484 operation by operation; the
+// library is compiled with -ffp-contract=off so no a*b+c is fused behind our back.
+#include "asw_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int p, int len)
+{  // BORDER_REFLECT (App. A-2)
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
+    return p;
+}
+__device__ __forceinline__ int reflect101_idx(int p, int len)
+{  // BORDER_REFLECT_101 (App. A-3)
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// filter2D(8UC3 -> CV_32F, [-3 0 3; -10 0 10; -3 0 3]), BORDER_REFLECT_101, on the image padded on
+// the left by `pad` REFLECT columns (pad = 0 for the left image, max_offset for the right one:
+// the reference filters right_border, M.cpp:450).  Values are exact integers, |v| <= 4080 -> int16.
+__global__ __launch_bounds__(256) void k_scharr_x(const uint8_t* __restrict__ img, int H, int W, int pad,
+                                                  short* __restrict__ grad /* [H][W+pad][3] */)
+{
+    const int Wb = W + pad;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (c >= Wb) return;
+    const int ym = reflect101_idx(y - 1, H), yp = reflect101_idx(y + 1, H);
+    const int cm = reflect_idx(reflect101_idx(c - 1, Wb) - pad, W), cp = reflect_idx(reflect101_idx(c + 1, Wb) - pad, W);
+    const uint8_t *r0 = img + (size_t)ym * W * 3, *r1 = img + (size_t)y * W * 3, *r2 = img + (size_t)yp * W * 3;
+    short* o = grad + ((size_t)y * Wb + c) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        int v = 3 * ((int)r0[cp * 3 + ch] - (int)r0[cm * 3 + ch]) + 10 * ((int)r1[cp * 3 + ch] - (int)r1[cm * 3 + ch]) +
+                3 * ((int)r2[cp * 3 + ch] - (int)r2[cm * 3 + ch]);
+        o[ch] = (short)v;
+    }
+}
+
+__device__ __forceinline__ float similarity_pixel(int c0, int c1, int c2, float g0, float g1, float g2, float rr, float rg,
+                                                  float thresCf, double thresC, double thresG, float thresGf)
+{
+    // colour term (u8): (c0+c1+c2)/3 -> round((min(255,c0+c1)+c2)/3); >thresC ? min(255, v+thresC) : 0  (M.cpp:459-465)
+    int t = min(255, c0 + c1);
+    int color = (t + c2 + 1) / 3;
+    int maskC = ((double)color > thresC) ? 1 : 0;
+    float tf = (float)(color * maskC) * 1.0f + 255.0f * (float)maskC * thresCf;  // addWeighted(m1,1,mask,thresC/255)
+    int cc_i = __float2int_rn(tf);                                                 // cvRound: to nearest even
+    cc_i = min(255, max(0, cc_i));
+    float cc = (float)cc_i;
+    // gradient term (f32): (g0+g1+g2)/3 = addWeighted(g0+g1, 1/3, g2, 1/3)   (M.cpp:473)
+    const float third = (float)(1.0 / 3.0);
+    float g01 = g0 + g1;
+    float g = g01 * third + g2 * third;
+    int maskG = ((double)g > thresG) ? 1 : 0;           // compare(>thresG)/255
+    float bit = (float)maskG, bit_not = (float)(255 - maskG);  // bitwise_not of a 0/1 mask: 255/254 (App. B-6)
+    float gm = g * bit;
+    float cg = bit_not * thresGf + gm;                  // scaleAdd(bit_not, thresG, gm)     (M.cpp:482)
+    return cc * rr + cg * rg;                           // addWeighted(cc, 1-reg, cg, reg)   (M.cpp:484)
+}
+
+// computeSimilarity, DISPARITY_LEFT + 3 channels (the only branch that can execute, App. B-7).
+// grid: (ceil(W/256), ceil(H/ROWS), numD); cost plane k <-> offset minD+k.
+constexpr int SIM_ROWS = 8;
+__global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                    const short* __restrict__ gL, const short* __restrict__ gR, int H, int W,
+                                                    int minD, int numD, float rr, float rg, float thresCf, double thresC,
+                                                    double thresG, float thresGf, float* __restrict__ cost)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.z, off = minD + k, max_off = minD + numD - 1, Wb = W + max_off;
+    if (x >= W) return;
+    const int cb = max_off - off + x;              // column in the padded right image (M.cpp:455)
+    const int xr = reflect_idx(cb - max_off, W);   // = reflect(x - off)
+    const int y0 = blockIdx.y * SIM_ROWS, y1 = min(H, y0 + SIM_ROWS);
+    for (int y = y0; y < y1; y++) {
+        const uint8_t* a = L + ((size_t)y * W + x) * 3;
+        const uint8_t* b = R + ((size_t)y * W + xr) * 3;
+        const short* ga = gL + ((size_t)y * W + x) * 3;
+        const short* gb = gR + ((size_t)y * Wb + cb) * 3;
+        int c0 = abs((int)a[0] - (int)b[0]), c1 = abs((int)a[1] - (int)b[1]), c2 = abs((int)a[2] - (int)b[2]);
+        float g0 = fabsf((float)ga[0] - (float)gb[0]), g1 = fabsf((float)ga[1] - (float)gb[1]),
+              g2 = fabsf((float)ga[2] - (float)gb[2]);
+        cost[((size_t)k * H + y) * W + x] = similarity_pixel(c0, c1, c2, g0, g1, g2, rr, rg, thresCf, thresC, thresG, thresGf);
+    }
+}
+
+// copyMakeBorder(plane, h,h,h,h, BORDER_REFLECT) for every plane (M.cpp:662-667)
+__global__ __launch_bounds__(256) void k_pad_reflect(const float* __restrict__ src, int H, int W, int h,
+                                                     float* __restrict__ dst)
+{
+    const int Hp = H + 2 * h, Wp = W + 2 * h;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= Wp) return;
+    dst[((size_t)k * Hp + y) * Wp + x] = src[((size_t)k * H + reflect_idx(y - h, H)) * W + reflect_idx(x - h, W)];
+}
+
+// ---- min/max reductions ------------------------------------------------------------------
+// order-preserving map float -> uint so that integer atomics give float min/max (any sign)
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ void block_minmax_commit(uint32_t lo, uint32_t hi, uint32_t* out2)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out2, lo);
+        atomicMax(out2 + 1, hi);
+    }
+}
+
+// per-slice min/max of a dense f32 volume [n][plane] -> ord[2*n] (init: {0xffffffff, 0})
+__global__ __launch_bounds__(256) void k_slice_minmax(const float* __restrict__ vol, size_t plane, uint32_t* __restrict__ ord)
+{
+    const int k = blockIdx.y;
+    const float* p = vol + (size_t)k * plane;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t o = f2ord(p[i]);
+        lo = min(lo, o);
+        hi = max(hi, o);
+    }
+    block_minmax_commit(lo, hi, ord + 2 * k);
+}
+
+// min/max over all bytes of a u8 buffer -> ord[2] (as float order keys)
+__global__ __launch_bounds__(256) void k_minmax_u8(const uint8_t* __restrict__ img, size_t n, uint32_t* __restrict__ ord)
+{
+    uint32_t lo = 255, hi = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v = img[i];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+    block_minmax_commit(f2ord((float)lo), f2ord((float)hi), ord);
+}
+
+// per-column min/max over rows and channels of an interleaved 3-channel u8 image -> colmm[2*W] (u8 values)
+__global__ __launch_bounds__(256) void k_col_minmax_u8(const uint8_t* __restrict__ img, int H, int W, int* __restrict__ colmm)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    int lo = 255, hi = 0;
+    for (int y = 0; y < H; y++) {
+        const uint8_t* p = img + ((size_t)y * W + x) * 3;
+        lo = min(lo, min((int)p[0], min((int)p[1], (int)p[2])));
+        hi = max(hi, max((int)p[0], max((int)p[1], (int)p[2])));
+    }
+    colmm[2 * x] = lo;
+    colmm[2 * x + 1] = hi;
+}
+
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+// normalize(src, dst, 0, 1, NORM_MINMAX, CV_32F) parameters (App. A-10):
+// scale = (max-min > DBL_EPSILON) ? 1/(max-min) : 0; shift = -min*scale; both cast to float.
+__device__ __forceinline__ float2 minmax_scale(double smin, double smax)
+{
+    double scale = (smax - smin > 2.220446049250313e-16) ? 1.0 / (smax - smin) : 0.0;
+    double shift = 0.0 - smin * scale;
+    return make_float2((float)scale, (float)shift);
+}
+
+// ord[2*n] -> scales[n] (float2 {a, b})
+__global__ void k_scales_from_ord(const uint32_t* __restrict__ ord, int n, float2* __restrict__ scales)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    scales[k] = minmax_scale((double)ord2f(ord[2 * k]), (double)ord2f(ord[2 * k + 1]));
+}
+
+// Guide scales of computeAdaptiveWeight_GuidedF (M.cpp:2907-2915): the 6-channel guide at disparity d is
+// [L, R shifted by d through the REFLECT pad]; its min/max run over L and over the right-image columns
+// the shifted view actually contains: reflect(x-d), x in [0,W)  ==  columns [0, max(d-1, W-1-d)] when
+// d < W (larger d: walk the reflection explicitly).
+__global__ void k_guide_scales_lr(const uint32_t* __restrict__ ordL, const int* __restrict__ colmmR, int W, int minD, int numD,
+                                  int disp_type, float2* __restrict__ scales)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= numD) return;
+    const int d = minD + k;
+    int lo = 255, hi = 0;
+    for (int x = 0; x < W; x++) {
+        int c = disp_type == ASW_DISPARITY_LEFT ? reflect_idx(x - d, W) : reflect_idx(x + d, W);
+        lo = min(lo, colmmR[2 * c]);
+        hi = max(hi, colmmR[2 * c + 1]);
+    }
+    double mn = fmin((double)ord2f(ordL[0]), (double)lo), mx = fmax((double)ord2f(ordL[1]), (double)hi);
+    scales[k] = minmax_scale(mn, mx);
+}
+
+__global__ void k_fill_u32(uint32_t* p, int n, uint32_t a, uint32_t b)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (i & 1) ? b : a;
+}
+
+}  // namespace
+
+int launch_scharr_x(hipStream_t s, const uint8_t* img, int H, int W, int pad, short* grad)
+{
+    dim3 grid((W + pad + 255) / 256, H);
+    hipLaunchKernelGGL(k_scharr_x, grid, dim3(256), 0, s, img, H, W, pad, grad);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const short* gL, const short* gR, int H, int W,
+                      int minD, int numD, double regularity, double thresC, double thresG, float* cost)
+{
+    dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, numD);
+    float rr = (float)(1.0 - regularity), rg = (float)regularity;  // regularityR, M.cpp:435
+    float thresCf = (float)(thresC * (1.0 / 255.0));
+    hipLaunchKernelGGL(k_similarity, grid, dim3(256), 0, s, L, R, gL, gR, H, W, minD, numD, rr, rg, thresCf, thresC, thresG,
+                       (float)thresG, cost);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_pad_reflect(hipStream_t s, const float* src, int n, int H, int W, int h, float* dst)
+{
+    dim3 grid((W + 2 * h + 255) / 256, H + 2 * h, n);
+    hipLaunchKernelGGL(k_pad_reflect, grid, dim3(256), 0, s, src, H, W, h, dst);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_slice_scales(hipStream_t s, const float* vol, int n, size_t plane, uint32_t* ord_scratch, float2* scales)
+{
+    hipLaunchKernelGGL(k_fill_u32, dim3((2 * n + 255) / 256), dim3(256), 0, s, ord_scratch, 2 * n, 0xffffffffu, 0u);
+    int bx = (int)((plane + 256 * 16 - 1) / (256 * 16));
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_slice_minmax, dim3(bx, n), dim3(256), 0, s, vol, plane, ord_scratch);
+    hipLaunchKernelGGL(k_scales_from_ord, dim3((n + 255) / 256), dim3(256), 0, s, ord_scratch, n, scales);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_u8_scale(hipStream_t s, const uint8_t* img, size_t nbytes, uint32_t* ord_scratch, float2* scale1)
+{
+    hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, s, ord_scratch, 2, 0xffffffffu, 0u);
+    int bx = (int)((nbytes + 256 * 64 - 1) / (256 * 64));
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_minmax_u8, dim3(bx), dim3(256), 0, s, img, nbytes, ord_scratch);
+    if (scale1) hipLaunchKernelGGL(k_scales_from_ord, dim3(1), dim3(256), 0, s, ord_scratch, 1, scale1);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t* shifted_img, int H, int W, int minD, int numD,
+                           int disp_type, uint32_t* ord_scratch, int* colmm_scratch, float2* scales)
+{
+    int rc = launch_u8_scale(s, ref_img, (size_t)H * W * 3, ord_scratch, nullptr);
+    if (rc != ASW_OK) return rc;
+    hipLaunchKernelGGL(k_col_minmax_u8, dim3((W + 255) / 256), dim3(256), 0, s, shifted_img, H, W, colmm_scratch);
+    hipLaunchKernelGGL(k_guide_scales_lr, dim3((numD + 255) / 256), dim3(256), 0, s, ord_scratch, colmm_scratch, W, minD, numD,
+                       disp_type, scales);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}

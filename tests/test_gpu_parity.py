@@ -114,3 +114,87 @@ def test_error_behaviour(ctx):
         with pytest.raises(asw.AswError) as e:
             ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
         assert e.value.status == asw.ERR_UNSUPPORTED_METHOD
+
+
+# ---------------------------------------------------------------- TAD C+G similarity, SAD cost
+@pytest.mark.parametrize("H,W,minD,numD,seed", [(9, 16, 0, 4, 1), (37, 70, 0, 24, 2), (20, 33, 3, 9, 3), (6, 10, 0, 25, 4)])
+def test_cost_similarity(ctx, oracle, H, W, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=8)
+    rc, want = oracle.compute_similarity(L, R, 0.4, 10, 50, 0, minD, numD)
+    got = np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, minD, numD))
+    assert rc == 0 and np.array_equal(got, want)          # same f32 operation order -> bit-exact
+    rc, wantp = oracle.compute_similarity(L, R, 0.4, 10, 50, 0, minD, numD, win=7)
+    gotp = np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, minD, numD, winSize=7))
+    assert gotp.shape == (numD, H + 6, W + 6) and np.array_equal(gotp, wantp)
+
+
+def test_cost_similarity_reference_errors(ctx):
+    L, R, _ = make_pair(12, 16, 4, seed=1)
+    assert ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, 4, winSize=6) == [] and asw.last_status() == asw.ERR_EVEN_WINDOW
+    with pytest.raises(asw.AswError) as e:   # RIGHT branch throws cv::Exception in the reference (App. B-7)
+        ctx.computeSimilarity(L, R, 0.4, 10, 50, RIGHT, 0, 4)
+    assert e.value.status == asw.ERR_UNSUPPORTED_LAYOUT
+
+
+def _ulp_stats(got, want):
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    scale = np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+    return float((d / scale).max()), int((got != want).sum())
+
+
+@pytest.mark.parametrize("H,W,dt,win,minD,numD", [(20, 40, 0, 5, 0, 6), (33, 300, 0, 15, 0, 10), (33, 300, 1, 15, 2, 5), (70, 64, 0, 7, 0, 3)])
+def test_cost_sad(ctx, oracle, H, W, dt, win, minD, numD):
+    L, R, _ = make_pair(H, W, 8, seed=H + W, block=16)
+    rc, want = oracle.cost_sad(L, R, dt, win, minD, numD)
+    got = np.stack(ctx.getCostSAD(L, R, dt, win, minD, numD))
+    rel, nbad = _ulp_stats(got, want)
+    # integer inputs: every f64 window sum is exact in any order -> bit-exact
+    assert rc == 0 and nbad == 0, (rel, nbad)
+
+
+@pytest.mark.parametrize("H,W,C,r,seed", [(18, 22, 3, 5, 4), (40, 300, 3, 15, 5), (40, 300, 6, 15, 6), (70, 50, 3, 6, 7)])
+def test_guided_filter(ctx, oracle, H, W, C, r, seed):
+    rng = np.random.default_rng(seed)
+    guide = rng.integers(0, 256, (H, W, C)).astype(np.uint8)
+    P = (rng.random((H, W), dtype=np.float32) * 150 + 5100).astype(np.float32)
+    rc, want = oracle.guided_filter(guide, P, r, 1e-6)
+    got = ctx.getGuidedFilter(guide, P, r, 1e-6)
+    assert rc == 0 and got.shape == want.shape
+    # q lives on the normalised [0,1] scale of P (M.cpp:2775): tolerance 1e-4 absolute there
+    assert np.abs(got - want).max() < 1e-4, np.abs(got - want).max()
+    # sliding f64 sums vs the oracle's direct sums: expect (almost) all values identical
+    assert (got != want).mean() < 0.02, (got != want).mean()
+
+
+def test_guided_filter_reference_errors(ctx):
+    rng = np.random.default_rng(0)
+    g1 = rng.integers(0, 256, (8, 8, 1)).astype(np.uint8)
+    with pytest.raises(asw.AswError) as e:   # 1-channel guide: empty Mat then cv::Exception (M.cpp:2732, 2847)
+        ctx.getGuidedFilter(g1, np.zeros((8, 8), np.float32), 3, 1e-6)
+    assert e.value.status == asw.ERR_UNSUPPORTED_LAYOUT
+    g3 = rng.integers(0, 256, (8, 8, 3)).astype(np.uint8)
+    assert ctx.getGuidedFilter(g3, np.zeros((8, 9), np.float32), 3, 1e-6) is None  # size mismatch -> Mat()
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (40, 270, 15, 0, 20, 4), (30, 100, 7, 2, 12, 5)])
+def test_guided2_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_guided2(L, R, 0, 1e-6, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD, H, W)
+    assert np.abs(v_got - v_want).max() < 1e-4
+    assert np.array_equal(d_got, d_want)
+    sel = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, win, minD, numD)
+    assert np.array_equal(sel, d_want)
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (40, 270, 15, 0, 12, 4), (30, 100, 7, 2, 9, 5)])
+def test_guided_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_guided(L, R, 0, 1e-6, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_GuidedF(L, R, LEFT, 1e-6, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and np.abs(v_got - v_want).max() < 1e-4
+    assert np.array_equal(d_got, d_want)
+    sel = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER, win, minD, numD)
+    assert np.array_equal(sel, d_want)
+    assert ctx.computeAdaptiveWeight_GuidedF(L, R, LEFT, 1e-6, 6, minD, numD) is None  # even window -> Mat()
