@@ -105,6 +105,8 @@ extern "C" void asw_destroy(asw_ctx* ctx)
     for (auto& kv : ctx->scratch) kv.second.release();
     ctx->bil.taps.release();
     ctx->bil.lut.release();
+    ctx->wm_lut2.release();
+    ctx->wm_wd.release();
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -392,6 +394,115 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     return ASW_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// geodesic ASW: computeAdaptiveWeight_geodesic (M.cpp:1436-1534)
+// ------------------------------------------------------------------------------------------
+static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+{
+    if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:1440-1443
+    if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;  // at<Vec3b>
+    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;  // RIGHT: next row
+    if (mp.win < 1 || mp.win > 35) return ASW_ERR_BAD_ARGUMENT;
+    const int H = f->rows, W = f->cols, nD = mp.numD + 1;  // inclusive range, M.cpp:1447,1467
+    const size_t plane = (size_t)H * W, cells = (size_t)mp.win * mp.win;
+    DevBuf& pl = ctx->buf("bgrxL");
+    DevBuf& pr = ctx->buf("bgrxR");
+    DevBuf& wl = ctx->buf("geoWL");
+    DevBuf& wr = ctx->buf("geoWR");
+    ASW_TRY(pl.ensure(plane * 4));
+    ASW_TRY(pr.ensure(plane * 4));
+    ASW_TRY(wl.ensure(plane * cells * 2));
+    ASW_TRY(wr.ensure(plane * cells * 2));
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = 0;
+    if (keep_volume) {
+        ASW_TRY(f->vol.ensure(plane * nD * 4));
+        f->vol_floats = plane * nD;
+    }
+    ASW_TRY(launch_pack_bgrx(ctx->stream, f->L.as<uint8_t>(), H, W, pl.as<uint32_t>()));
+    ASW_TRY(launch_pack_bgrx(ctx->stream, f->R.as<uint8_t>(), H, W, pr.as<uint32_t>()));
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pl.as<uint32_t>(), H, W, mp.win, 3, wl.as<uint16_t>()));  // M.cpp:1464
+    ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pr.as<uint32_t>(), H, W, mp.win, 3, wr.as<uint16_t>()));  // M.cpp:1465
+    ASW_TRY(launch_asw_geodesic(ctx->stream, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
+                                mp.win, mp.minD, nD, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->timing.aggregate_launches = 3;
+    return ASW_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weighted-median ASW: computeAdaptiveWeight_WeightedMedian (M.cpp:3228-3383)
+// ------------------------------------------------------------------------------------------
+static int ensure_wmedian_tables(asw_ctx* ctx, int win, double rate_s, double rate_r)
+{
+    if (ctx->wm_rate_r != rate_r || !ctx->wm_lut2.p) {
+        // computeColorWeightGau: exp((d0+d1+d2)/rateR*(-1)) == exp(addWeighted(d0+d1, a, d2, a)) with
+        // a = (float)(-1/rateR) (M.cpp:3177-3179); cv::exp restated as expf
+        std::vector<float> lut((size_t)511 * 256);
+        const float al = (float)((1.0 / rate_r) * (-1.0));
+        for (int m = 0; m < 511; m++)
+            for (int c = 0; c < 256; c++) {
+                float arg = (float)m * al + (float)c * al;
+                lut[(size_t)m * 256 + c] = expf(arg);
+            }
+        ASW_TRY(ctx->wm_lut2.ensure(lut.size() * 4));
+        ASW_HIP_TRY(hipMemcpyAsync(ctx->wm_lut2.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->wm_rate_r = rate_r;
+    }
+    if (ctx->wm_rate_s != rate_s || ctx->wm_win != win || !ctx->wm_wd.p) {
+        // computeSpaceWeightGau (M.cpp:3207-3226)
+        const int h = win / 2;
+        std::vector<float> wd((size_t)win * win);
+        const float al = (float)((1.0 / rate_s) * (-1.0));
+        for (int y = 0; y < win; y++)
+            for (int x = 0; x < win; x++) {
+                float v = (float)((x - h) * (x - h)) + (float)((y - h) * (y - h));
+                wd[(size_t)x * win + y] = expf(v * al);
+            }
+        ASW_TRY(ctx->wm_wd.ensure(wd.size() * 4));
+        ASW_HIP_TRY(hipMemcpyAsync(ctx->wm_wd.p, wd.data(), wd.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->wm_rate_s = rate_s;
+        ctx->wm_win = win;
+    }
+    return ASW_OK;
+}
+
+static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+{
+    if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:3238-3241
+    if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;  // App. B-7 / B-13
+    if (mp.win < 1 || mp.win > 15) return ASW_ERR_BAD_ARGUMENT;  // 256-slot sorting network (win*win <= 256)
+    const int H = f->rows, W = f->cols, n = mp.numD, cells = mp.win * mp.win;
+    const int max_off = mp.minD + mp.numD - 1, Wb = W + max_off;
+    const size_t plane = (size_t)H * W;
+    ASW_TRY(ensure_wmedian_tables(ctx, mp.win, mp.rate_s, mp.rate_r));
+    DevBuf& raw = ctx->buf("g_raw");
+    DevBuf& wl = ctx->buf("wmWL");
+    DevBuf& wr = ctx->buf("wmWR");
+    ASW_TRY(raw.ensure(plane * n * 4));
+    ASW_TRY(wl.ensure(plane * cells * 4));
+    ASW_TRY(wr.ensure((size_t)H * Wb * cells * 4));
+    ASW_TRY(f->vol.ensure(plane * n * 4));
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = keep_volume ? plane * n : 0;
+    const uint8_t* dL = f->L.as<uint8_t>();
+    const uint8_t* dR = f->R.as<uint8_t>();
+    ASW_TRY(build_similarity_volume(ctx, dL, dR, H, W, mp.minD, n, 0.4, 10, 50, raw.as<float>()));  // M.cpp:3250
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ASW_TRY(launch_wm_weights(ctx->stream, dL, H, W, 0, mp.win, ctx->wm_lut2.as<float>(), ctx->wm_wd.as<float>(), wl.as<float>()));
+    ASW_TRY(launch_wm_weights(ctx->stream, dR, H, W, max_off, mp.win, ctx->wm_lut2.as<float>(), nullptr, wr.as<float>()));
+    ASW_TRY(launch_wmedian(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off,
+                           f->vol.as<float>()));
+    ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3365-3381
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->timing.aggregate_launches = 4;
+    return ASW_OK;
+}
+
 static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume)
 {
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
@@ -400,8 +511,10 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     int rc;
     switch (algorithm) {  // M.cpp:49-87
     case ASW_ALG_ADAPTIVE_WEIGHT: rc = run_bilateral(ctx, f, mp, keep_volume); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC: rc = run_geodesic(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, false); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, true); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN: rc = run_wmedian(ctx, f, mp, keep_volume); break;
     default: rc = ASW_ERR_UNSUPPORTED_METHOD; break;
     }
     if (rc != ASW_OK) return rc;
@@ -660,11 +773,53 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     return ASW_OK;
 }
 
+extern "C" int asw_aggregate_geodesic(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                      int disparity_type, int win_size, int min_disparity, int num_disparity,
+                                      float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC, mp, cost_volume_out);
+}
+
+extern "C" int asw_geodesic_dist(asw_ctx* ctx, const asw_image* img, float* out, int win_size, int iter_time)
+{
+    if (!ctx || !out) return ASW_ERR_BAD_ARGUMENT;
+    ASW_TRY(check_u8_image(img));
+    if (win_size % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:1394-1397
+    if (img->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (win_size < 1 || win_size > 35 || iter_time < 0) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const int H = img->rows, W = img->cols, cells = win_size * win_size;
+    const size_t plane = (size_t)H * W;
+    DevBuf& di = ctx->buf("stageL");
+    DevBuf& px = ctx->buf("bgrxL");
+    DevBuf& pf = ctx->buf("geoPlanesF");
+    DevBuf& wo = ctx->buf("geoWindows");
+    ASW_TRY(upload_image(ctx, img, di));
+    ASW_TRY(px.ensure(plane * 4));
+    ASW_TRY(pf.ensure(plane * cells * 4));
+    ASW_TRY(wo.ensure(plane * cells * 4));
+    ASW_TRY(launch_pack_bgrx(ctx->stream, di.as<uint8_t>(), H, W, px.as<uint32_t>()));
+    ASW_TRY(launch_geodesic_weights_f32(ctx->stream, px.as<uint32_t>(), H, W, win_size, iter_time, pf.as<float>()));
+    ASW_TRY(launch_planes_to_windows(ctx->stream, pf.as<float>(), H, W, cells, wo.as<float>()));
+    ASW_HIP_TRY(hipMemcpyAsync(out, wo.p, plane * cells * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
+extern "C" int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                     int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,
+                                     int num_disparity, float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    mp.rate_s = rate_s; mp.rate_r = rate_r;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN, mp, cost_volume_out);
+}
+
 // ---- not built yet in this revision: report honestly instead of silently falling back ----
 #define ASW_TODO(name, ...) \
     extern "C" int name(__VA_ARGS__) { return ASW_ERR_UNSUPPORTED_METHOD; }
 
-ASW_TODO(asw_aggregate_geodesic, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, int, int, int, float*)
-ASW_TODO(asw_aggregate_wmedian, asw_ctx*, const asw_image*, const asw_image*, asw_image*, int, int, double, double, int, int, float*)
-ASW_TODO(asw_geodesic_dist, asw_ctx*, const asw_image*, float*, int, int)
 ASW_TODO(asw_stereo_match_batch, int, const asw_image*, const asw_image*, asw_image*, int, int, int, int, int, int, const int*)

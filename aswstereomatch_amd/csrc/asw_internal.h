@@ -53,6 +53,10 @@ struct asw_ctx {
     std::vector<Frame> frames;
     std::map<std::string, DevBuf> scratch;  // named grow-only scratch buffers
     BilateralTables bil;
+    // weighted-median tables: exp() LUT of the colour weight per rateR, space kernel per (win, rateS)
+    DevBuf wm_lut2, wm_wd;
+    double wm_rate_r = -1, wm_rate_s = -1;
+    int wm_win = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // total start/stop, aggregate start/stop
     asw_timing timing = {0, 0, 0, 0};
     DevBuf& buf(const char* name) { return scratch[name]; }
@@ -108,3 +112,17 @@ struct GuidedLaunch {
     float* q;               // out [n][H][W]
 };
 int launch_guided(hipStream_t s, const GuidedLaunch& a);
+
+// ---- geodesic support weights (k_geodesic.hip) ----
+int launch_pack_bgrx(hipStream_t s, const uint8_t* bgr, int H, int W, uint32_t* out);
+int launch_geodesic_weights_u16(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, uint16_t* planes);
+int launch_geodesic_weights_f32(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, float* planes);
+int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, int cells, float* out);
+int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
+                        int H, int W, int win, int minD, int nD, float* vol, float* disp);
+
+// ---- weighted median (k_wmedian.hip) ----
+int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,
+                      float* out);
+int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
+                   int max_off, float* out);

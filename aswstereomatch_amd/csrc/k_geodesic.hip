@@ -1,0 +1,330 @@
+// Geodesic-distance support weights and aggregation
+// (getColorDist / getWinGeoDist / getGeodesicDist / computeAdaptiveWeight_geodesic, M.cpp:1321-1534).
+//
+// Weights.  For every pixel the reference relaxes a (win+2)^2 window of L1-colour geodesic distances
+// with three raster passes (M.cpp:1339-1388): iterations 0 and 1 are the BACKWARD pass (R, BR, B, BL
+// neighbours), iteration 2 the FORWARD pass (L, UL, U, UR) -- App. B-8.  A raster pass is a fixed point
+// of itself (every cell already holds the minimum over the monotone paths the pass can build), so
+// repeating it changes nothing: the kernel runs one backward and one forward sweep.  All values are
+// exact small integers (steps <= 765), FLT_MAX + d == FLT_MAX in f32 is modelled by an integer INF
+// that min() never prefers.  One thread owns one pixel; a sweep keeps two window rows of distances and
+// of packed BGRX pixels in registers, the L1 colour distance is a single v_sad_u8.  Window state lives
+// in cell-major planes W[cell][y][x] (coalesced, and exactly the tap-major layout the aggregation
+// wants).
+//
+// Aggregation (M.cpp:1467-1531).  num += fl(fl(wL*wR)*c), den += fl(wL*wR) with f32 products and f64
+// sums.  Every addend is an integer below 2^40 and there are win^2 <= 2^11 of them, so every partial
+// sum is an integer below 2^53: the f64 sums are exact in ANY order and E = num/den is bit-identical
+// to the reference whatever the schedule.  Tiling follows the bilateral kernel (64x4 pixel tile, DC
+// disparities per thread, taps outer); wR rows are staged through LDS from the weight planes.
+#include "asw_internal.h"
+
+namespace {
+
+constexpr uint32_t GEO_INF = 0x40000000u;
+
+__device__ __forceinline__ int reflect_idx(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_pack_bgrx(const uint8_t* __restrict__ bgr, size_t n, uint32_t* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)bgr[3 * i] | ((uint32_t)bgr[3 * i + 1] << 8) | ((uint32_t)bgr[3 * i + 2] << 16);
+}
+
+__device__ __forceinline__ uint32_t cdist(uint32_t a, uint32_t b) { return __builtin_amdgcn_sad_u8(a, b, 0u); }
+
+// One thread = one pixel.  WIN is the (odd) window size; planes: [WIN*WIN][H][W] (u16 or f32).
+template <int WIN, typename OutT>
+__global__ __launch_bounds__(64) void k_geodesic_weights(const uint32_t* __restrict__ img, int H, int W, int backward,
+                                                         int forward, OutT* __restrict__ planes)
+{
+    constexpr int h = WIN / 2, N = WIN + 2;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
+    int col[N];  // image column of window column c (BORDER_REFLECT, pad h+1: M.cpp:1404)
+#pragma unroll
+    for (int c = 0; c < N; c++) col[c] = reflect_idx(x - h - 1 + c, W);
+
+    auto store = [&](int r, int c, uint32_t v) {
+        OutT o;
+        if constexpr (sizeof(OutT) == 2) o = (OutT)(v >= GEO_INF ? 65535u : v);
+        else o = v >= GEO_INF ? 3.402823466e+38f : (float)v;
+        planes[(size_t)((r - 1) * WIN + (c - 1)) * plane + pix] = o;
+    };
+
+    // ---- backward sweep: r = WIN..1, c = WIN..1; neighbours R, BR, B, BL (M.cpp:1367-1387) ----
+    uint32_t dprev[N], pprev[N];  // distances / pixels of row r+1
+#pragma unroll
+    for (int c = 0; c < N; c++) dprev[c] = GEO_INF;  // ring row WIN+1 (M.cpp:1416)
+    {
+        const uint32_t* row = img + (size_t)reflect_idx(y + h + 1, H) * W;
+#pragma unroll
+        for (int c = 0; c < N; c++) pprev[c] = row[col[c]];
+    }
+    if (backward) {
+        for (int r = WIN; r >= 1; r--) {
+            uint32_t dcur[N], pcur[N];
+            const uint32_t* row = img + (size_t)reflect_idx(y - h - 1 + r, H) * W;
+#pragma unroll
+            for (int c = 0; c < N; c++) pcur[c] = row[col[c]];
+            dcur[N - 1] = GEO_INF;
+            dcur[0] = GEO_INF;
+#pragma unroll
+            for (int c = WIN; c >= 1; c--) {
+                uint32_t v = (r == h + 1 && c == h + 1) ? 0u : GEO_INF;  // M.cpp:1416-1417
+                v = min(v, dcur[c + 1] + cdist(pcur[c + 1], pcur[c]));   // R
+                v = min(v, dprev[c + 1] + cdist(pprev[c + 1], pcur[c])); // BR
+                v = min(v, dprev[c] + cdist(pprev[c], pcur[c]));         // B
+                v = min(v, dprev[c - 1] + cdist(pprev[c - 1], pcur[c])); // BL
+                v = min(v, GEO_INF);                                      // FLT_MAX + d == FLT_MAX
+                dcur[c] = v;
+                store(r, c, v);
+            }
+#pragma unroll
+            for (int c = 0; c < N; c++) { dprev[c] = dcur[c]; pprev[c] = pcur[c]; }
+        }
+    } else {
+        for (int r = WIN; r >= 1; r--)
+#pragma unroll
+            for (int c = WIN; c >= 1; c--) store(r, c, (r == h + 1 && c == h + 1) ? 0u : GEO_INF);
+    }
+
+    // ---- forward sweep: r = 1..WIN, c = 1..WIN; neighbours L, UL, U, UR (M.cpp:1343-1362) ----
+    if (forward) {
+#pragma unroll
+        for (int c = 0; c < N; c++) dprev[c] = GEO_INF;  // ring row 0
+        {
+            const uint32_t* row = img + (size_t)reflect_idx(y - h - 1, H) * W;
+#pragma unroll
+            for (int c = 0; c < N; c++) pprev[c] = row[col[c]];
+        }
+        for (int r = 1; r <= WIN; r++) {
+            uint32_t dcur[N], pcur[N];
+            const uint32_t* row = img + (size_t)reflect_idx(y - h - 1 + r, H) * W;
+#pragma unroll
+            for (int c = 0; c < N; c++) pcur[c] = row[col[c]];
+            dcur[0] = GEO_INF;
+            dcur[N - 1] = GEO_INF;
+#pragma unroll
+            for (int c = 1; c <= WIN; c++) {
+                OutT o = planes[(size_t)((r - 1) * WIN + (c - 1)) * plane + pix];
+                uint32_t v;
+                if constexpr (sizeof(OutT) == 2) v = (o == 65535u) ? GEO_INF : (uint32_t)o;
+                else v = (o > 1e30f) ? GEO_INF : (uint32_t)o;
+                v = min(v, dcur[c - 1] + cdist(pcur[c - 1], pcur[c]));   // L
+                v = min(v, dprev[c - 1] + cdist(pprev[c - 1], pcur[c])); // UL
+                v = min(v, dprev[c] + cdist(pprev[c], pcur[c]));         // U
+                v = min(v, dprev[c + 1] + cdist(pprev[c + 1], pcur[c])); // UR
+                v = min(v, GEO_INF);
+                dcur[c] = v;
+                store(r, c, v);
+            }
+#pragma unroll
+            for (int c = 0; c < N; c++) { dprev[c] = dcur[c]; pprev[c] = pcur[c]; }
+        }
+    }
+}
+
+// planes [cells][H][W] f32 -> reference layout [H][W][win][win] (map<Point,Mat>, M.cpp:1420)
+__global__ __launch_bounds__(256) void k_planes_to_windows(const float* __restrict__ planes, size_t npix, int cells,
+                                                           float* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * cells) return;
+    size_t p = i / cells;
+    int c = (int)(i - p * cells);
+    out[i] = planes[(size_t)c * npix + p];
+}
+
+// ---------------------------------------------------------------------------------------------
+// aggregation
+// ---------------------------------------------------------------------------------------------
+constexpr int TW = 64, TH = 4, GDC = 8, GG = 5;  // tile, disparities per thread, taps per staging group
+
+struct GeoParams {
+    int H, W, win, minD, nD;
+};
+
+template <int DC>
+__device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __restrict__ imgR,
+                                          const uint16_t* __restrict__ wL, const uint16_t* __restrict__ wR,
+                                          float* __restrict__ vol, unsigned char* smem, int c0, double& bestE, float& bestD)
+{
+    const int win = p.win, h = win / 2, H = p.H, W = p.W;
+    const int TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
+    constexpr int SWR = TW + DC - 1;
+    // LDS carve-up (sized on the host for DC = GDC)
+    float* sC = reinterpret_cast<float*>(smem);                                  // [TR*LW][DC]
+    float* sWR = sC + (size_t)TR * LW * GDC;                                     // [GG][TH][TW+GDC-1]
+    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));  // [TR][LW]
+    uint32_t* sR = sL + TR * LW;                                                 // [TR][RWmax]
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int d0 = p.minD + c0;
+    const int RW = TW + 2 * h + DC - 1;
+    const int sRx0 = x0 - h - (d0 + DC - 1);
+    const size_t plane = (size_t)H * W;
+
+    __syncthreads();
+    for (int i = tid; i < TR * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
+        sR[r * RWmax + c] = imgR[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+    // colour-L1 cost tile: C[r][c][dd] = |L(ny,nx) - R(ny, max(0,nx-d))|_1   (M.cpp:1490)
+    for (int i = tid; i < TR * LW; i += 256) {
+        int r = i / LW, c = i - r * LW;
+        int nx = min(max(x0 - h + c, 0), W - 1);
+        uint32_t pl = sL[i];
+#pragma unroll
+        for (int dd = 0; dd < DC; dd++) {
+            int xr = max(0, nx - (d0 + dd));
+            int tc = min(max(xr - sRx0, 0), RW - 1);  // tile is clamp-replicated
+            sC[(size_t)i * DC + dd] = (float)cdist(pl, sR[r * RWmax + tc]);
+        }
+    }
+
+    double num[DC], den[DC];
+#pragma unroll
+    for (int dd = 0; dd < DC; dd++) { num[dd] = 0.0; den[dd] = 0.0; }
+    const int x = x0 + tx, y = y0 + ty;
+    const int xc = min(x, W - 1), yc = min(y, H - 1);
+    const uint16_t* myWL = wL + (size_t)yc * W + xc;
+    const int ntaps = win * win;
+
+    for (int g0 = 0; g0 < ntaps; g0 += GG) {
+        const int ng = min(GG, ntaps - g0);
+        __syncthreads();
+        // right-image weights of the tile rows for xr = max(0, x - d): j = tx + (DC-1) - dd
+        for (int i = tid; i < ng * TH * SWR; i += 256) {
+            int tt = i / (TH * SWR), rem = i - tt * (TH * SWR);
+            int row = rem / SWR, j = rem - row * SWR;
+            int xr = min(max(x0 - d0 - (DC - 1) + j, 0), W - 1);
+            int yy = min(y0 + row, H - 1);
+            sWR[(tt * TH + row) * (TW + GDC - 1) + j] = (float)wR[(size_t)(g0 + tt) * plane + (size_t)yy * W + xr];
+        }
+        __syncthreads();
+        for (int tt = 0; tt < ng; tt++) {
+            const int t = g0 + tt;
+            const int j = t / win, i = t - j * win;  // window row j, column i (M.cpp:1481-1483)
+            const float wl = (float)myWL[(size_t)t * plane];
+            const float* cell = sC + (size_t)((ty + j) * LW + (tx + i)) * DC;
+            const float* wr = sWR + (tt * TH + ty) * (TW + GDC - 1) + tx + (DC - 1);
+#pragma unroll
+            for (int dd = 0; dd < DC; dd++) {
+                float ab = wl * wr[-dd];   // f32
+                float abc = ab * cell[dd]; // f32 (M.cpp:1488-1490)
+                num[dd] = num[dd] + (double)abc;
+                den[dd] = den[dd] + (double)ab;
+            }
+        }
+    }
+    if (x < W && y < H) {
+#pragma unroll
+        for (int dd = 0; dd < DC; dd++) {
+            double E = num[dd] / den[dd];  // 0/0 -> NaN for windows flat in both images (App. B-9)
+            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + x] = (float)E;
+            if (E < bestE) { bestE = E; bestD = (float)(d0 + dd); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
+                                                      const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
+                                                      const uint16_t* __restrict__ wR, float* __restrict__ vol,
+                                                      float* __restrict__ disp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int h = p.win / 2, TR = TH + 2 * h, LW = TW + 2 * h;
+    float* sC = reinterpret_cast<float*>(smem);
+    float* sWR = sC + (size_t)TR * LW * GDC;
+    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));
+    const int tid = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = tid; i < TR * LW; i += 256) {
+        int r = i / LW, c = i - r * LW;
+        int yy = min(max(y0 - h + r, 0), p.H - 1), xx = min(max(x0 - h + c, 0), p.W - 1);
+        sL[i] = imgL[(size_t)yy * p.W + xx];
+    }
+    double bestE = 1.7976931348623157e308;
+    float bestD = 0.0f;
+    int c0 = 0;
+    for (; c0 + 8 <= p.nD; c0 += 8) geo_chunk<8>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    if (p.nD - c0 >= 4) { geo_chunk<4>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
+    if (p.nD - c0 >= 2) { geo_chunk<2>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
+    if (p.nD - c0 >= 1) { geo_chunk<1>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
+    const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
+    if (x < p.W && y < p.H) disp[(size_t)y * p.W + x] = bestD;
+}
+
+template <int WIN, typename OutT>
+int launch_weights_t(hipStream_t s, const uint32_t* img, int H, int W, int backward, int forward, OutT* planes)
+{
+    dim3 grid((W + 63) / 64, H);
+    hipLaunchKernelGGL((k_geodesic_weights<WIN, OutT>), grid, dim3(64), 0, s, img, H, W, backward, forward, planes);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+template <typename OutT>
+int launch_weights(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, OutT* planes)
+{
+    // iterations 0,1 -> backward, 2,3 -> forward, others nothing (iterCount/2, M.cpp:1341,1365)
+    const int backward = iter >= 1, forward = iter >= 3;
+    switch (win) {
+#define GEO_CASE(w) case w: return launch_weights_t<w, OutT>(s, img, H, W, backward, forward, planes);
+        GEO_CASE(1) GEO_CASE(3) GEO_CASE(5) GEO_CASE(7) GEO_CASE(9) GEO_CASE(11) GEO_CASE(13) GEO_CASE(15) GEO_CASE(17)
+        GEO_CASE(19) GEO_CASE(21) GEO_CASE(23) GEO_CASE(25) GEO_CASE(27) GEO_CASE(29) GEO_CASE(31) GEO_CASE(33) GEO_CASE(35)
+#undef GEO_CASE
+    default: return ASW_ERR_BAD_ARGUMENT;  // windows above 35 are not instantiated
+    }
+}
+
+}  // namespace
+
+int launch_pack_bgrx(hipStream_t s, const uint8_t* bgr, int H, int W, uint32_t* out)
+{
+    size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(k_pack_bgrx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bgr, n, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_geodesic_weights_u16(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, uint16_t* planes)
+{
+    return launch_weights<uint16_t>(s, img, H, W, win, iter, planes);
+}
+
+int launch_geodesic_weights_f32(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, float* planes)
+{
+    return launch_weights<float>(s, img, H, W, win, iter, planes);
+}
+
+int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, int cells, float* out)
+{
+    size_t n = (size_t)H * W * cells;
+    hipLaunchKernelGGL(k_planes_to_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes, (size_t)H * W, cells, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
+                        int H, int W, int win, int minD, int nD, float* vol, float* disp)
+{
+    GeoParams p{H, W, win, minD, nD};
+    const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
+    size_t lds = (size_t)TR * LW * GDC * 4 + (size_t)GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
+    if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
+    if (lds > 64 * 1024)
+        ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_asw_geodesic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH);
+    hipLaunchKernelGGL(k_asw_geodesic, grid, dim3(256), lds, s, p, imgL, imgR, wL, wR, vol, disp);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}

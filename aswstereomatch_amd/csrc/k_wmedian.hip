@@ -1,0 +1,220 @@
+// Weighted-median aggregation (computeColorWeightGau / computeSpaceWeightGau /
+// computeAdaptiveWeight_WeightedMedian, M.cpp:3139-3383, DISPARITY_LEFT branch).
+//
+// Per (pixel, d) the reference inserts the win^2 (cost, weight) pairs of the support window into a
+// std::multimap<float,float> (= stable sort by cost, insertion order = row-major window order), walks it
+// accumulating weights in f64 until the partial sum exceeds half of the total weight, and returns the
+// cost of the element BEFORE the crossing one (or the first one), M.cpp:3276-3304 (App. B-13).
+//
+// GPU mapping: one wavefront per pixel, looping over d.  The 225 pairs of a 15x15 window sit 4 per lane
+// (256 slots, padded with +inf keys / zero weights).  A 64-bit key (order-preserving cost bits << 32 |
+// window index) makes a plain bitonic network a STABLE sort: 15 intra-lane and 21 cross-lane
+// compare-exchange steps (DPP/bpermute shuffles), no payload is moved -- the weight of a sorted
+// element is fetched from LDS by its window index afterwards.  Prefix sums are a per-lane chain plus a
+// wavefront scan in f64.  Window weights are read in the reference's own per-pixel layout
+// [y][x][cell] (900 contiguous bytes per pixel -> coalesced): the left one premultiplied by the space
+// kernel once per frame, the right one for the REFLECT-padded right image (M.cpp:3246, 3263).
+// exp() values come from host-built tables (same libm as the oracle), so weights are bit-identical.
+#include "asw_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
+    return p;
+}
+
+// colour weights of every window cell: out[(y*Wimg + c)*n + cell]
+//   pad = 0:  left image, multiplied by the space kernel wd[cell]           (M.cpp:3262, 3274)
+//   pad > 0:  right image seen through its REFLECT left pad of `pad` columns; the window itself is
+//             taken from that padded image padded again by h (M.cpp:3156, 3263)
+__global__ __launch_bounds__(256) void k_wm_weights(const uint8_t* __restrict__ img, int H, int W, int pad, int win,
+                                                    const float* __restrict__ lut2 /* [511][256] */,
+                                                    const float* __restrict__ wd /* [n] or null */, float* __restrict__ out)
+{
+    const int n = win * win, h = win / 2, Wb = W + pad;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * Wb * n) return;
+    const int cell = (int)(i % n);
+    const size_t pc = i / n;
+    const int cb = (int)(pc % Wb), y = (int)(pc / Wb);
+    const int j = cell / win, ii = cell - j * win;
+    const uint8_t* c0 = img + ((size_t)y * W + reflect_idx(cb - pad, W)) * 3;
+    const int cc = reflect_idx(cb - h + ii, Wb);
+    const uint8_t* p = img + ((size_t)reflect_idx(y - h + j, H) * W + reflect_idx(cc - pad, W)) * 3;
+    const int d0 = abs((int)p[0] - (int)c0[0]), d1 = abs((int)p[1] - (int)c0[1]), d2 = abs((int)p[2] - (int)c0[2]);
+    float w = lut2[(d0 + d1) * 256 + d2];
+    if (wd) w = w * wd[cell];
+    out[i] = w;
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_xor((int)lo, mask);
+    hi = (uint32_t)__shfl_xor((int)hi, mask);
+    return ((u64)hi << 32) | lo;
+}
+
+// 256-key ascending bitonic sort across one wavefront, element e = lane*4 + r
+__device__ __forceinline__ void bitonic256(u64 (&key)[4], int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+                const int lm = j >> 2;
+                const bool up = ((lane * 4) & k) == 0;   // k >= 8 here: direction depends on the lane only
+                const bool lower = (lane & lm) == 0;
+                const bool take_min = (up == lower);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    u64 o = shfl_xor_u64(key[r], lm);
+                    u64 mn = key[r] < o ? key[r] : o, mx = key[r] < o ? o : key[r];
+                    key[r] = take_min ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = r ^ j;
+                    if (q > r) {
+                        const bool up = ((lane * 4 + r) & k) == 0;
+                        u64 a = key[r], b = key[q];
+                        u64 mn = a < b ? a : b, mx = a < b ? b : a;
+                        key[r] = up ? mn : mx;
+                        key[q] = up ? mx : mn;
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr int WM_WAVES = 4;
+
+__global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost /* raw [numD][H][W] */,
+                                                 const float* __restrict__ wLd /* [H][W][n] */,
+                                                 const float* __restrict__ wRb /* [H][Wb][n] */, int H, int W, int win,
+                                                 int numD, int max_off, float* __restrict__ out /* [numD][H][W] */)
+{
+    __shared__ float sW[WM_WAVES][256];
+    __shared__ uint32_t sK[WM_WAVES][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t pix = (size_t)blockIdx.x * WM_WAVES + wv;
+    if (pix >= (size_t)H * W) return;  // whole wave exits together
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    const int n = win * win, h = win / 2, Wb = W + max_off;
+    const size_t plane = (size_t)H * W;
+
+    float wl[4];
+    int off[4];  // offset of the element's cost sample inside a cost plane (REFLECT-padded window, M.cpp:665,3273)
+    bool valid[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = lane * 4 + r;
+        valid[r] = e < n;
+        const int ee = valid[r] ? e : 0;
+        const int j = ee / win, i = ee - j * win;
+        off[r] = reflect_idx(y + j - h, H) * W + reflect_idx(x + i - h, W);
+        wl[r] = valid[r] ? wLd[pix * n + ee] : 0.0f;
+    }
+
+    for (int d = 0; d < numD; d++) {
+        const int cb = x - d + numD - 1;  // weightWinsR[y][x - offset + numDisparity - 1], M.cpp:3274
+        const float* wr = wRb + ((size_t)y * Wb + cb) * n;
+        const float* cp = cost + (size_t)d * plane;
+        float w[4];
+        u64 key[4];
+        double s_loc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int e = lane * 4 + r;
+            if (valid[r]) {
+                w[r] = wl[r] * wr[e];  // (wL .mul wd) .mul wR, f32
+                key[r] = ((u64)f2ord(cp[off[r]]) << 32) | (uint32_t)e;
+            } else {
+                w[r] = 0.0f;
+                key[r] = ~0ull;
+            }
+            s_loc += (double)w[r];
+            sW[wv][e] = w[r];
+        }
+        // cv::sum(weight_img_win)[0] / 2  (f64 accumulation, M.cpp:3284)
+        double tot = s_loc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        const double half = tot / 2;
+
+        bitonic256(key, lane);
+
+        // weights in sorted order, inclusive prefix sums in f64
+        double pre[4];
+        double run = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t idx = (uint32_t)key[r] & 0xffu;
+            run += (double)sW[wv][idx];   // same-wave LDS: written above by this wave, in program order
+            pre[r] = run;
+            sK[wv][lane * 4 + r] = (uint32_t)(key[r] >> 32);
+        }
+        double incl = run;  // wave inclusive scan of the lane totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            double t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const double excl = incl - run;
+        int first = 4;
+#pragma unroll
+        for (int r = 3; r >= 0; r--)
+            if (excl + pre[r] > half) first = r;
+        const unsigned long long ball = __ballot(first < 4);
+        float res = 0.0f;
+        if (ball) {
+            const int fl = __ffsll((long long)ball) - 1;
+            const int fr = __shfl(first, fl);
+            const int kpos = fl * 4 + fr;
+            const int take = kpos == 0 ? 0 : kpos - 1;  // predecessor of the crossing element (M.cpp:3293-3301)
+            res = ord2f(sK[wv][take]);
+        }
+        if (lane == 0) out[(size_t)d * plane + pix] = res;
+    }
+}
+
+}  // namespace
+
+int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,
+                      float* out)
+{
+    size_t n = (size_t)H * (W + pad) * win * win;
+    hipLaunchKernelGGL(k_wm_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, H, W, pad, win, lut2, wd, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
+                   int max_off, float* out)
+{
+    if (win * win > 256) return ASW_ERR_BAD_ARGUMENT;
+    size_t npix = (size_t)H * W;
+    hipLaunchKernelGGL(k_wmedian, dim3((unsigned)((npix + WM_WAVES - 1) / WM_WAVES)), dim3(256), 0, s, cost, wLd, wRb, H, W, win,
+                       numD, max_off, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}

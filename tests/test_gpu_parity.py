@@ -198,3 +198,69 @@ def test_guided_parity(ctx, oracle, H, W, win, minD, numD, seed):
     sel = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER, win, minD, numD)
     assert np.array_equal(sel, d_want)
     assert ctx.computeAdaptiveWeight_GuidedF(L, R, LEFT, 1e-6, 6, minD, numD) is None  # even window -> Mat()
+
+
+# ---------------------------------------------------------------- geodesic ASW
+@pytest.mark.parametrize("H,W,win,iters", [(9, 9, 5, 3), (20, 70, 7, 3), (16, 40, 15, 3), (12, 20, 5, 1), (12, 20, 5, 2), (12, 20, 3, 0)])
+def test_geodesic_dist(ctx, oracle, H, W, win, iters):
+    L, _, _ = make_pair(H, W, 4, seed=win + H, block=8)
+    rc, want = oracle.geodesic_dist(L, win, iters)
+    got = ctx.getGeodesicDist(L, win, iters)
+    assert rc == 0 and np.array_equal(got, want)   # exact integers / FLT_MAX
+
+
+def test_geodesic_dist_even_window(ctx):
+    L, _, _ = make_pair(8, 8, 2, seed=1)
+    assert ctx.getGeodesicDist(L, 4) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [
+    (24, 40, 5, 0, 8, 3), (37, 130, 7, 0, 20, 4), (20, 70, 15, 2, 33, 5), (12, 64, 3, 0, 80, 6)])
+def test_geodesic_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_geodesic(L, R, 0, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD + 1, H, W)
+    assert np.array_equal(v_got, v_want, equal_nan=True)   # all f64 sums are exact -> E bit-identical
+    assert np.array_equal(d_got, d_want)
+    sel = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GEODESIC, win, minD, numD)
+    assert np.array_equal(sel, d_want)
+
+
+def test_geodesic_flat_windows_are_nan(ctx, oracle):
+    # windows flat in both images: weights all 0 -> 0/0 = NaN -> never selected -> build value 0 (App. B-9)
+    L = np.full((12, 24, 3), 77, np.uint8)
+    R = L.copy()
+    rc, d_want, v_want = oracle.asw_geodesic(L, R, 0, 5, 0, 4, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, 5, 0, 4, return_cost_volume=True)
+    assert np.isnan(v_want).all() and np.isnan(v_got).all() and (d_got == 0).all() and np.array_equal(d_got, d_want)
+
+
+# ---------------------------------------------------------------- weighted-median ASW
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(16, 24, 5, 0, 6, 3), (20, 70, 7, 0, 12, 4), (14, 40, 15, 1, 9, 5), (10, 12, 3, 0, 20, 6)])
+def test_wmedian_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=8)
+    rc, d_want, v_want = oracle.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, win, 10, 10, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD, H, W)
+    assert np.array_equal(v_got, v_want)    # the median is one of the (bit-exact) input costs
+    assert np.array_equal(d_got, d_want)
+    sel = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, win, minD, numD)
+    assert np.array_equal(sel, d_want)
+
+
+def test_wmedian_flat_ties(ctx, oracle):
+    # heavy cost ties (identical images, d=0 exact match): stable multimap order decides the crossing
+    L, _, _ = make_pair(16, 32, 4, seed=8, block=8)
+    R = L.copy()
+    rc, d_want, v_want = oracle.asw_wmedian(L, R, 0, 5, 10, 10, 0, 5, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 5, 10, 10, 0, 5, return_cost_volume=True)
+    assert np.array_equal(v_got, v_want) and np.array_equal(d_got, d_want)
+
+
+def test_all_methods_recover_shift_k6(ctx):
+    d0 = 5
+    L, R = shifted_pair(40, 64, d0)
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_MEDIAN):
+        d = ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
+        assert (d[8:-8, 16:-8] == d0).all(), alg
