@@ -25,6 +25,7 @@ __all__ = [
     "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
     "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
     "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
+    "stereoMatchingBatch",
     "AswError",
 ]
 
@@ -276,6 +277,37 @@ class Context:
         self._lib.asw_get_timing(self._h, C.byref(t))
         return {"total_ms": t.total_ms, "aggregate_ms": t.aggregate_ms, "cost_ms": t.cost_ms,
                 "aggregate_launches": t.aggregate_launches}
+
+
+def stereoMatchingBatch(lefts, rights, disparityType, algorithmType, winSize=15, minDisparity=0, numDisparity=64,
+                        device_ids=None):
+    """asw_stereo_match_batch: frame i -> device device_ids[i % len(device_ids)], one host thread per device."""
+    lib = _lib.lib()
+    n = len(lefts)
+    if device_ids is None:
+        device_ids = list(range(max(1, lib.asw_device_count())))
+    keep = []
+    L = (AswImage * n)()
+    R = (AswImage * n)()
+    D = (AswImage * n)()
+    outs = []
+    for i in range(n):
+        li, la = _image(lefts[i])
+        ri, ra = _image(rights[i])
+        o = np.zeros((la.shape[0], la.shape[1]), np.float32)
+        di, _ = _image(o, 5)
+        L[i], R[i], D[i] = li, ri, di
+        keep.append((la, ra))
+        outs.append(o)
+    devs = (C.c_int * len(device_ids))(*device_ids)
+    rc = lib.asw_stereo_match_batch(n, L, R, D, int(disparityType), int(algorithmType), winSize, minDisparity, numDisparity,
+                                    len(device_ids), devs)
+    _state.status = rc
+    if rc in _SILENT:
+        return None
+    if rc != 0:
+        raise AswError(rc, "asw_stereo_match_batch")
+    return outs
 
 
 # ---- module-level functions with the reference's names, bound to a lazily created default context ----

@@ -817,9 +817,3 @@ extern "C" int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const 
     mp.rate_s = rate_s; mp.rate_r = rate_r;
     return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN, mp, cost_volume_out);
 }
-
-// ---- not built yet in this revision: report honestly instead of silently falling back ----
-#define ASW_TODO(name, ...) \
-    extern "C" int name(__VA_ARGS__) { return ASW_ERR_UNSUPPORTED_METHOD; }
-
-ASW_TODO(asw_stereo_match_batch, int, const asw_image*, const asw_image*, asw_image*, int, int, int, int, int, int, const int*)

@@ -38,32 +38,56 @@ def algorithmic_bytes(W, H, n_cand):
     return 2 * W * H * 3 + W * H * n_cand * 4 + W * H * 4
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, L, R, gpu_disp, alg):
-    """The oracle (CPU restatement of the reference method) timed on this host, bounded sample."""
+    """The oracle (CPU restatement of the reference method) timed on this host on a bounded sample."""
     from oracle import asw_oracle as O
 
-    cores = O.max_threads()
+    cores = min(host_cores(), O.max_threads())
     O.set_threads(cores)
     H, W = L.shape[:2]
-    if alg != 2:
-        return None
-    # calibrate on 2 rows, then size the sample for ~args.cpu_seconds of wall time
-    y0 = H // 2
+    D, win = args.disp, args.win
+    if alg == 2:
+        # rows of the very frame the GPU just processed (classic ASW is local: a row needs only its window)
+        y0 = H // 2
+        t = time.time()
+        O.asw_classic(L, R, 30, 20, 0, win, 0, D, rows=(y0, y0 + cores))
+        per_row = (time.time() - t) / cores
+        rows = int(max(cores, min(H - y0, args.cpu_seconds / max(per_row, 1e-9))))
+        rows = max(cores, rows // cores * cores)
+        t = time.time()
+        rc, d, _ = O.asw_classic(L, R, 30, 20, 0, win, 0, D, rows=(y0, y0 + rows))
+        dt = time.time() - t
+        ok = bool(np.array_equal(d[y0:y0 + rows], gpu_disp[y0:y0 + rows])) if gpu_disp is not None else None
+        return {"value": round(rows * W / dt / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                "sample": "rows %d..%d (%d of %d) of one %dx%d D=%d win=%d frame, oracle/asw_oracle.c "
+                          "orc_asw_classic_rows, OpenMP %d threads, %.1f s" % (y0, y0 + rows, rows, H, W, H, D, win, cores, dt),
+                "gpu_rows_match_oracle": ok}
+    # the other methods are not row-local (per-slice normalisation, whole-frame tables): time a smaller frame
+    from aswstereomatch_amd.synth import make_pair
+
+    fn = {4: lambda a, b: O.asw_geodesic(a, b, 0, win, 0, D), 7: lambda a, b: O.asw_guided(a, b, 0, 1e-6, win, 0, D),
+          8: lambda a, b: O.asw_guided2(a, b, 0, 1e-6, win, 0, D), 10: lambda a, b: O.asw_wmedian(a, b, 0, win, 10, 10, 0, D)}[alg]
+    sw, sh = {4: (621, 188), 7: (1280, 720), 8: (1920, 1080), 10: (311, 94)}[alg]  # sized for ~10-20 s on 16 cores
+    sw, sh = min(sw, W), min(sh, H)
+    Ls, Rs, _ = make_pair(sh, sw, min(D, sw // 2), seed=4321)
     t = time.time()
-    O.asw_classic(L, R, 30, 20, 0, args.win, 0, args.disp, rows=(y0, y0 + cores))
-    per_row = (time.time() - t) / cores
-    rows = int(max(cores, min(H - y0, args.cpu_seconds / max(per_row, 1e-9))))
-    rows = max(cores, rows // cores * cores)
-    t = time.time()
-    rc, d, _ = O.asw_classic(L, R, 30, 20, 0, args.win, 0, args.disp, rows=(y0, y0 + rows))
+    rc = fn(Ls, Rs)[0]
     dt = time.time() - t
-    ok = bool(np.array_equal(d[y0:y0 + rows], gpu_disp[y0:y0 + rows])) if gpu_disp is not None else None
-    return {
-        "value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
-        "sample": "rows %d..%d (%d of %d) of one %dx%d D=%d win=%d frame, oracle/asw_oracle.c "
-                  "orc_asw_classic_rows, OpenMP %d threads, %.1f s" % (y0, y0 + rows, rows, H, W, H, args.disp, args.win, cores, dt),
-        "gpu_rows_match_oracle": ok,
-    }
+    return {"value": round(sw * sh / dt / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": "one %dx%d D=%d win=%d synthetic frame (full method, rc=%d), oracle/asw_oracle.c, OpenMP %d threads, %.1f s"
+                      % (sw, sh, D, win, rc, cores, dt)}
 
 
 def main():
@@ -89,15 +113,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     import aswstereomatch_amd as asw
+    from aswstereomatch_amd.dist import Group
     from aswstereomatch_amd.synth import make_pair
+
+    group = Group(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     alg, ncand_fn, label = WORKLOADS[args.workload]
     W, H, D = args.width, args.height, args.disp
@@ -113,8 +133,7 @@ def main():
             frames.append((L, R))
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
         ctx._lib.asw_synchronize(ctx._h)
 
@@ -143,10 +162,7 @@ def main():
         launches += n
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = group.max_over_ranks(elapsed)
 
     if rank == 0:
         frames_total = args.frames * args.steps * world
@@ -192,9 +208,7 @@ def main():
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,66 @@
+"""Golden fixtures (tests/golden/asw_golden_v1.npz, made by tests/golden/make_golden.py from the oracle).
+CPU: the oracle still reproduces them bit for bit.  GPU: the HIP path reproduces them (C-ABI calls)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "asw_golden_v1.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD, allow_pickle=False)
+
+
+def test_oracle_reproduces_golden(oracle, gold):
+    L, R = gold["L"], gold["R"]
+    H, W, D, WIN, _ = [int(v) for v in gold["params"]]
+    assert np.array_equal(oracle.bgr2gray(L), gold["gray_L"])
+    assert np.array_equal(oracle.compute_ad(L, R, 0, 0, D)[1], gold["ad"])
+    assert np.array_equal(oracle.compute_tad(L, R, 0, 30, 0, D)[1], gold["tad"])
+    assert np.array_equal(oracle.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1], gold["similarity"])
+    assert np.array_equal(oracle.cost_sad(L, R, 0, WIN, 0, D)[1], gold["sad"])
+    assert np.array_equal(oracle.geodesic_dist(L, WIN, 3)[1], gold["geodesic_dist_L"])
+    for name, fn in [("classic", lambda: oracle.asw_classic(L, R, 30, 20, 0, WIN, 0, D, want_vol=True)),
+                     ("geodesic", lambda: oracle.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
+                     ("guided", lambda: oracle.asw_guided(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
+                     ("guided2", lambda: oracle.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
+                     ("wmedian", lambda: oracle.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True))]:
+        rc, disp, vol = fn()
+        assert rc == 0 and np.array_equal(disp, gold[name + "_disp"]), name
+        assert np.array_equal(vol, gold[name + "_vol"], equal_nan=True), name
+
+
+def test_golden_is_meaningful(gold):
+    # the synthetic pair has a recoverable ground truth: every method gets most interior pixels right
+    gt = gold["gt"]
+    for name in ("classic", "geodesic", "guided2", "wmedian"):
+        ok = (gold[name + "_disp"][6:-6, 14:-6] == gt[6:-6, 14:-6]).mean()
+        assert ok > 0.5, (name, ok)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(gold):
+    import aswstereomatch_amd as asw
+
+    ctx = asw.Context(0)
+    L, R = gold["L"], gold["R"]
+    H, W, D, WIN, _ = [int(v) for v in gold["params"]]
+    A, LEFT = asw.StereoMatchingAlgorithms, asw.DISPARITY_LEFT
+    assert np.array_equal(ctx.bgr2gray(L), gold["gray_L"])
+    assert np.array_equal(np.stack(ctx.computeAD(L, R, LEFT, 0, D)), gold["ad"])
+    assert np.array_equal(np.stack(ctx.computeTAD(L, R, LEFT, 30, 0, D)), gold["tad"])
+    assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, D)), gold["similarity"])
+    assert np.array_equal(np.stack(ctx.getCostSAD(L, R, LEFT, WIN, 0, D)), gold["sad"])
+    assert np.array_equal(ctx.getGeodesicDist(L, WIN, 3), gold["geodesic_dist_L"])
+    exact = {"classic": A.ADAPTIVE_WEIGHT, "geodesic": A.ADAPTIVE_WEIGHT_GEODESIC, "wmedian": A.ADAPTIVE_WEIGHT_MEDIAN}
+    for name, alg in exact.items():
+        d, v = ctx.stereoMatching(L, R, LEFT, alg, WIN, 0, D, return_cost_volume=True)
+        assert np.array_equal(d, gold[name + "_disp"]), name
+        assert np.array_equal(v, gold[name + "_vol"], equal_nan=True), name
+    for name, alg in {"guided": A.ADAPTIVE_WEIGHT_GUIDED_FILTER, "guided2": A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2}.items():
+        d, v = ctx.stereoMatching(L, R, LEFT, alg, WIN, 0, D, return_cost_volume=True)
+        assert np.array_equal(d, gold[name + "_disp"]), name          # WTA index bit-exact
+        assert np.abs(v - gold[name + "_vol"]).max() < 1e-4, name      # float cost volume within 1e-4 (north_star)
+    ctx.close()

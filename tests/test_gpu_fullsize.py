@@ -1,0 +1,105 @@
+"""BASELINE.json full-size configurations on the GPU.  The oracle cannot finish these in seconds, so they
+are checked through (a) oracle comparison on a band of rows where the method is row-local, and (b)
+size-independent properties: WTA consistency of the returned cost volume, exact recovery of a known
+shift (K6), run-to-run bit determinism, batch == single-frame results."""
+import numpy as np
+import pytest
+
+import aswstereomatch_amd as asw
+from aswstereomatch_amd.synth import make_pair, shifted_pair
+
+pytestmark = pytest.mark.gpu
+A = asw.StereoMatchingAlgorithms
+LEFT = asw.DISPARITY_LEFT
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = asw.Context(0)
+    yield c
+    c.close()
+
+
+def _wta_consistent(disp, vol, minD=0):
+    """The cost at the chosen disparity is the minimum over d (NaN never chosen); among equal f32 minima the
+    chosen one is not later than the first (strict '<' in ascending d on the un-rounded cost)."""
+    v = np.where(np.isnan(vol), np.inf, vol)
+    mn = v.min(axis=0)
+    idx = (disp - minD).astype(np.int64)
+    chosen = np.take_along_axis(v, idx[None], axis=0)[0]
+    has = np.isfinite(mn)
+    return bool((chosen[has] == mn[has]).all()) and bool((disp[~has] == 0).all())
+
+
+def test_c2_cones_shape_classic_win35(ctx, oracle):
+    # configs[1]: 450x375, D=64, bilateral ASW with a 35x35 window
+    L, R, _ = make_pair(375, 450, 64, seed=2)
+    d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 35, 0, 64, return_cost_volume=True)
+    assert v.shape == (65, 375, 450) and _wta_consistent(d, v)
+    for rows in ((0, 4), (180, 184), (371, 375)):   # top edge, interior, bottom edge
+        rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 35, 0, 64, want_vol=True, rows=rows)
+        assert rc == 0
+        assert np.array_equal(d[rows[0]:rows[1]], dw[rows[0]:rows[1]])
+        assert np.array_equal(v[:, rows[0]:rows[1]], vw[:, rows[0]:rows[1]])
+
+
+def test_c5_frame_1080p_classic_rows_vs_oracle(ctx, oracle):
+    # one frame of configs[4]: 1920x1080, D=128, win 15
+    L, R, _ = make_pair(1080, 1920, 128, seed=1234)
+    d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 15, 0, 128, return_cost_volume=True)
+    assert v.shape == (129, 1080, 1920) and _wta_consistent(d, v)
+    for rows in ((0, 3), (537, 541), (1077, 1080)):
+        rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 15, 0, 128, want_vol=True, rows=rows)
+        assert np.array_equal(d[rows[0]:rows[1]], dw[rows[0]:rows[1]])
+        assert np.array_equal(v[:, rows[0]:rows[1]], vw[:, rows[0]:rows[1]])
+    d2 = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 15, 0, 128)
+    assert np.array_equal(d, d2)   # bit-deterministic
+
+
+def test_c3_1080p_guided2_properties(ctx):
+    # configs[2]: 1920x1080, D=128, guided-filter ASW
+    L, R, gt = make_pair(1080, 1920, 128, seed=77)
+    d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 128, return_cost_volume=True)
+    assert v.shape == (128, 1080, 1920) and np.isfinite(v).all()
+    assert np.array_equal(np.argmin(v, axis=0).astype(np.float32), d)   # WTA == first minimum of the returned volume
+    assert d.max() <= 127                                                # numD candidates only (K7)
+    inner = (slice(32, -32), slice(160, -32))
+    assert (d[inner] == gt[inner]).mean() > 0.6                          # recovers most of the ground truth
+    d2 = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 128)
+    assert np.array_equal(d, d2)
+
+
+def test_c3_shift_recovery_all_methods_mid_size(ctx):
+    d0 = 37
+    L, R = shifted_pair(270, 480, d0, seed=9)
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_MEDIAN):
+        d = ctx.stereoMatching(L, R, LEFT, alg, 15, 0, 64)
+        assert (d[16:-16, 80:-16] == d0).all(), alg
+
+
+def test_c4_kitti_shape_geodesic_and_wmedian(ctx, oracle):
+    # configs[3]: 1242x375, D=192, geodesic ASW + weighted-median
+    L, R, gt = make_pair(375, 1242, 192, seed=5)
+    d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GEODESIC, 15, 0, 192, return_cost_volume=True)
+    assert v.shape == (193, 375, 1242) and _wta_consistent(d, v)
+    inner = (slice(16, -16), slice(200, -16))
+    assert (d[inner] == gt[inner]).mean() > 0.5
+    # geodesic weights of the full frame, exact, on a few pixels (the windows are local)
+    w = ctx.getGeodesicDist(L[100:140, 300:380], 15, 3)
+    rc, ww = oracle.geodesic_dist(L[100:140, 300:380], 15, 3)
+    assert np.array_equal(w, ww)
+    dm, vm = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, 15, 0, 192, return_cost_volume=True)
+    assert vm.shape == (192, 375, 1242) and np.array_equal(np.argmin(vm, axis=0).astype(np.float32), dm)
+    # the median is always one of the window's input costs
+    costs = np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, 192))
+    assert np.isin(vm[::37, ::11, ::13], costs).all()
+
+
+def test_batch_equals_single_frames(ctx):
+    frames = [make_pair(96, 160, 24, seed=100 + i)[:2] for i in range(5)]
+    outs = asw.stereoMatchingBatch([f[0] for f in frames], [f[1] for f in frames], LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7,
+                                   0, 24, device_ids=[0, 0])   # two host threads, both on device 0
+    assert len(outs) == 5
+    for (L, R), o in zip(frames, outs):
+        assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7, 0, 24))
+    assert asw.stereoMatchingBatch([], [], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) == []
