@@ -1,0 +1,247 @@
+// aswMethods_mi355x.hpp -- C++ surface of the reference (aswStereoMatch/methods/aswMethods.h, "M.h") on
+// top of the C-ABI of asw_mi355x.h.  Header-only.
+//
+//  * With OpenCV available (#include <opencv2/core.hpp> found, or ASW_WITH_OPENCV defined) the functions
+//    take and return cv::Mat with EXACTLY the reference signatures, so a maintainer of the reference
+//    replaces `#include "methods/aswMethods.h"` by this header and links libasw_mi355x.so
+//    (INTEGRATION.md).
+//  * Without OpenCV the same functions are available on asw::Mat, a minimal stand-in for the part of
+//    cv::Mat the path uses (rows, cols, type, step, data, empty()).
+//
+// Error behaviour mirrors the reference: where it returns silently or an empty Mat (size mismatch, even
+// window) so does the shim; statuses with no reference equivalent (HIP error, unsupported method) throw
+// std::runtime_error -- the reference throws cv::Exception in comparable situations (M.cpp:103-116).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "asw_mi355x.h"
+
+#if !defined(ASW_WITH_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#define ASW_WITH_OPENCV 1
+#endif
+#endif
+#ifdef ASW_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+// parametersStereo.h:4-24 -- same names and values (skip when the reference header is also included)
+#ifndef ASW_REFERENCE_ENUMS_DEFINED
+#define ASW_REFERENCE_ENUMS_DEFINED
+enum DisparityType { DISPARITY_LEFT = 0, DISPARITY_RIGHT = 1 };
+enum StereoMatchingAlgorithms {
+    BM = 0, SGBM = 1, ADAPTIVE_WEIGHT = 2, ADAPTIVE_WEIGHT_8DIRECT = 3, ADAPTIVE_WEIGHT_GEODESIC = 4,
+    ADAPTIVE_WEIGHT_BILATERAL_GRID = 5, ADAPTIVE_WEIGHT_BLO1 = 6, ADAPTIVE_WEIGHT_GUIDED_FILTER = 7,
+    ADAPTIVE_WEIGHT_GUIDED_FILTER_2 = 8, ADAPTIVE_WEIGHT_GUIDED_FILTER_3 = 9, ADAPTIVE_WEIGHT_MEDIAN = 10, NCC = 11
+};
+#endif
+
+namespace asw {
+
+// ---- minimal Mat used when OpenCV is absent --------------------------------------------------------
+struct Mat {
+    int rows = 0, cols = 0, channels_ = 0, depth_ = ASW_8U;
+    size_t step = 0;
+    std::shared_ptr<std::vector<uint8_t>> buf;
+    uint8_t* data = nullptr;
+    Mat() {}
+    Mat(int r, int c, int depth, int ch) { create(r, c, depth, ch); }
+    void create(int r, int c, int depth, int ch)
+    {
+        rows = r; cols = c; depth_ = depth; channels_ = ch;
+        step = (size_t)c * ch * (depth == ASW_32F ? 4 : 1);
+        buf = std::make_shared<std::vector<uint8_t>>(step * r);
+        data = buf->data();
+    }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int channels() const { return channels_; }
+    int depth() const { return depth_; }
+};
+
+namespace detail {
+
+inline asw_ctx* context()
+{
+    // one lazily created context per host thread (contexts are not shared between threads)
+    struct Holder {
+        asw_ctx* c = nullptr;
+        ~Holder() { if (c) asw_destroy(c); }
+    };
+    static thread_local Holder h;
+    if (!h.c) {
+        int rc = asw_create(0, &h.c);
+        if (rc != ASW_OK) throw std::runtime_error(std::string("asw_create: ") + asw_status_string(rc));
+    }
+    return h.c;
+}
+
+inline bool silent(int rc) { return rc == ASW_ERR_SIZE_MISMATCH || rc == ASW_ERR_EVEN_WINDOW; }
+inline void raise_unless_ok(int rc, const char* what)
+{
+    if (rc != ASW_OK && !silent(rc)) throw std::runtime_error(std::string(what) + ": " + asw_status_string(rc));
+}
+
+#ifdef ASW_WITH_OPENCV
+typedef cv::Mat MatT;
+inline asw_image view(const cv::Mat& m)
+{
+    asw_image v{m.data, m.rows, m.cols, m.channels(), m.depth() == CV_32F ? ASW_32F : (m.depth() == CV_8U ? ASW_8U : -1), m.step[0]};
+    return v;
+}
+inline cv::Mat make(int r, int c, int depth, int ch) { return cv::Mat(r, c, CV_MAKETYPE(depth == ASW_32F ? CV_32F : CV_8U, ch)); }
+#else
+typedef asw::Mat MatT;
+inline asw_image view(const asw::Mat& m) { return asw_image{m.data, m.rows, m.cols, m.channels_, m.depth_, m.step}; }
+inline asw::Mat make(int r, int c, int depth, int ch) { return asw::Mat(r, c, depth, ch); }
+#endif
+
+template <typename Fn>
+inline MatT aggregate(const MatT& l, const MatT& r, Fn fn, const char* what)
+{
+    if (l.empty() || r.empty()) return MatT();
+    MatT disp = make(l.rows, l.cols, ASW_32F, 1);
+    asw_image li = view(l), ri = view(r), di = view(disp);
+    int rc = fn(context(), &li, &ri, &di);
+    raise_unless_ok(rc, what);
+    return rc == ASW_OK ? disp : MatT();  // empty Mat where the reference returns Mat()
+}
+
+template <typename T, typename Fn>
+inline void cost_volume(const MatT& l, const MatT& r, std::vector<MatT>& out, int n, int depth, int pad, Fn fn, const char* what)
+{
+    if (!out.empty()) out.clear();  // M.cpp:222-225
+    if (l.empty() || r.empty() || n <= 0) return;
+    const int H = l.rows + 2 * pad, W = l.cols + 2 * pad;
+    std::vector<T> vol((size_t)n * H * W);
+    asw_image li = view(l), ri = view(r);
+    int rc = fn(context(), &li, &ri, vol.data());
+    raise_unless_ok(rc, what);
+    if (rc != ASW_OK) return;  // silent return of the reference: cost_ds stays empty
+    for (int k = 0; k < n; k++) {
+        MatT m = make(H, W, depth, 1);
+        asw_image mi = view(m);
+        for (int y = 0; y < H; y++)
+            std::memcpy((uint8_t*)mi.data + (size_t)y * mi.step, vol.data() + ((size_t)k * H + y) * W, (size_t)W * sizeof(T));
+        out.push_back(m);
+    }
+}
+
+}  // namespace detail
+}  // namespace asw
+
+// ---------------------------------------------------------------------------------------------------
+// The reference's functions (M.h:91-182), global namespace like the reference
+// ---------------------------------------------------------------------------------------------------
+typedef asw::detail::MatT AswMat;
+
+// M.h:91-92 / M.cpp:46-88
+inline void stereoMatching(AswMat srcLeft, AswMat srcRight, AswMat& disparityMap, DisparityType disparityType,
+                           StereoMatchingAlgorithms algorithmType, int winSize = 15, int minDisparity = 0, int numDisparity = 64)
+{
+    AswMat d = asw::detail::aggregate(srcLeft, srcRight, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_stereo_match(c, l, r, o, (int)disparityType, (int)algorithmType, winSize, minDisparity, numDisparity, nullptr);
+    }, "stereoMatching");
+    disparityMap = d;  // `disparityMap = computeAdaptiveWeight...(...)`, M.cpp:58-82 (empty Mat on silent errors)
+}
+
+// M.h:101-102
+inline void computeAD(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_ds, DisparityType dispType = DISPARITY_LEFT,
+                      int minDisparity = 0, int numDisparity = 30)
+{
+    asw::detail::cost_volume<uint8_t>(leftImg, rightImg, cost_ds, numDisparity, ASW_8U, 0, [&](asw_ctx* c, asw_image* l, asw_image* r, uint8_t* v) {
+        return asw_cost_ad(c, l, r, v, (int)dispType, minDisparity, numDisparity);
+    }, "computeAD");
+}
+
+// M.h:105-106
+inline void computeTAD(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_ds, DisparityType dispType = DISPARITY_LEFT,
+                       int threshold_T = 30, int minDisparity = 0, int numDisparity = 30)
+{
+    asw::detail::cost_volume<uint8_t>(leftImg, rightImg, cost_ds, numDisparity, ASW_8U, 0, [&](asw_ctx* c, asw_image* l, asw_image* r, uint8_t* v) {
+        return asw_cost_tad(c, l, r, v, (int)dispType, threshold_T, minDisparity, numDisparity);
+    }, "computeTAD");
+}
+
+// M.h:109-111
+inline void computeSimilarity(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_d_imgs, double regularity, double thresC,
+                              double thresG, DisparityType dispType, int minDisparity, int numDisparity)
+{
+    asw::detail::cost_volume<float>(leftImg, rightImg, cost_d_imgs, numDisparity, ASW_32F, 0, [&](asw_ctx* c, asw_image* l, asw_image* r, float* v) {
+        return asw_cost_similarity(c, l, r, v, regularity, thresC, thresG, (int)dispType, 0, minDisparity, numDisparity);
+    }, "computeSimilarity");
+}
+
+// M.h:112-114 (padded overload)
+inline void computeSimilarity(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_d_imgs, double regularity, double thresC,
+                              double thresG, DisparityType dispType, int winSize, int minDisparity, int numDisparity)
+{
+    if (winSize % 2 == 0) return;  // M.cpp:654-657: returns before touching cost_d_imgs
+    asw::detail::cost_volume<float>(leftImg, rightImg, cost_d_imgs, numDisparity, ASW_32F, winSize / 2, [&](asw_ctx* c, asw_image* l, asw_image* r, float* v) {
+        return asw_cost_similarity(c, l, r, v, regularity, thresC, thresG, (int)dispType, winSize, minDisparity, numDisparity);
+    }, "computeSimilarity(padded)");
+}
+
+// M.h:133-134
+inline AswMat computeAdaptiveWeight(AswMat leftImg, AswMat rightImg, double gamma_c = 30, double gamma_g = 2,
+                                    DisparityType dispType = DISPARITY_LEFT, int winSize = 7, int minDisparity = 186,
+                                    int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_bilateral(c, l, r, o, gamma_c, gamma_g, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight");
+}
+
+// M.h:142-143
+inline AswMat computeAdaptiveWeight_geodesic(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, int winSize = 7,
+                                             int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_geodesic(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_geodesic");
+}
+
+// M.h:165
+inline AswMat getGuidedFilter(AswMat guidedImg, AswMat inputP, int r, double eps)
+{
+    if (guidedImg.rows != inputP.rows || guidedImg.cols != inputP.cols) return AswMat();  // M.cpp:2768-2769
+    AswMat q = asw::detail::make(inputP.rows, inputP.cols, ASW_32F, 1);
+    asw_image gi = asw::detail::view(guidedImg), pi = asw::detail::view(inputP), qi = asw::detail::view(q);
+    if (pi.depth != ASW_32F || pi.step != (size_t)pi.cols * 4 || qi.step != (size_t)qi.cols * 4)
+        throw std::runtime_error("getGuidedFilter: inputP must be a continuous CV_32FC1 Mat");
+    int rc = asw_guided_filter(asw::detail::context(), &gi, (const float*)pi.data, (float*)qi.data, r, eps);
+    asw::detail::raise_unless_ok(rc, "getGuidedFilter");
+    return rc == ASW_OK ? q : AswMat();
+}
+
+// M.h:166-168
+inline AswMat computeAdaptiveWeight_GuidedF(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 1e-8,
+                                            int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_guided(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_GuidedF");
+}
+
+// M.h:169-171
+inline AswMat computeAdaptiveWeight_GuidedF_2(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 1e-8,
+                                              int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_guided2(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_GuidedF_2");
+}
+
+// M.h:179-182
+inline AswMat computeAdaptiveWeight_WeightedMedian(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT,
+                                                   int winSize = 35, double sampleRateS = 10, double sampleRateR = 10,
+                                                   int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_wmedian(c, l, r, o, (int)dispType, winSize, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_WeightedMedian");
+}
