@@ -318,7 +318,8 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
 // and computeAdaptiveWeight_GuidedF (M.cpp:2867-2963, SAD cost, 6-channel guide [L, R shifted by d])
 // ------------------------------------------------------------------------------------------
 static int build_similarity_volume(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int W, int minD, int numD,
-                                   double regularity, double thresC, double thresG, float* cost)
+                                   double regularity, double thresC, double thresG, float* cost,
+                                   uint32_t* ord_scratch = nullptr, float2* scales = nullptr)
 {
     const int max_off = minD + numD - 1;
     DevBuf& gl = ctx->buf("scharrL");
@@ -328,7 +329,7 @@ static int build_similarity_volume(asw_ctx* ctx, const uint8_t* dL, const uint8_
     ASW_TRY(launch_scharr_x(ctx->stream, dL, H, W, 0, gl.as<short>()));
     ASW_TRY(launch_scharr_x(ctx->stream, dR, H, W, max_off, gr.as<short>()));  // gradient of the PADDED right image
     return launch_similarity(ctx->stream, dL, dR, gl.as<short>(), gr.as<short>(), H, W, minD, numD, regularity, thresC, thresG,
-                             cost);
+                             cost, ord_scratch, scales);
 }
 
 static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume, bool variant2)
@@ -345,17 +346,21 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     DevBuf& ord = ctx->buf("g_ord");
     DevBuf& psc = ctx->buf("g_pscales");
     DevBuf& gsc = ctx->buf("g_gscales");
-    DevBuf& meanI = ctx->buf("g_meanI");
-    DevBuf& den = ctx->buf("g_den");
+    DevBuf& stats = ctx->buf("g_stats");
     DevBuf& ab = ctx->buf("g_ab");
+    DevBuf& pxa = ctx->buf("bgrxL");
+    DevBuf& pxb = ctx->buf("bgrxR");
     const int nstat = variant2 ? 1 : n;
     ASW_TRY(raw.ensure(plane * n * 4));
+    DevBuf& parts = ctx->buf("g_parts");
+    ASW_TRY(parts.ensure(similarity_parts_words(H, W, n) * 4));
     ASW_TRY(ord.ensure((size_t)(2 * n + 2) * 4));
     ASW_TRY(psc.ensure((size_t)n * sizeof(float2)));
     ASW_TRY(gsc.ensure((size_t)n * sizeof(float2)));
-    ASW_TRY(meanI.ensure(plane * C * nstat * 4));
-    ASW_TRY(den.ensure(plane * C * nstat * 4));
-    ASW_TRY(ab.ensure(plane * (C + 1) * n * 4));
+    ASW_TRY(stats.ensure(guided_stats_floats(C, nstat, H, W) * 4));
+    ASW_TRY(ab.ensure(guided_ab_floats(C, n, H, W) * 4));
+    ASW_TRY(pxa.ensure(plane * 4));
+    ASW_TRY(pxb.ensure(plane * 4));
     ASW_TRY(f->vol.ensure(plane * n * 4));  // q volume: always needed for the WTA pass
     ASW_TRY(f->disp.ensure(plane * 4));
     f->vol_floats = keep_volume ? plane * n : 0;
@@ -363,10 +368,13 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     const uint8_t* dR = f->R.as<uint8_t>();
 
     GuidedLaunch a;
-    a.mode = variant2 ? 0 : 1; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
-    a.guideA = dL; a.guideB = dR;
+    a.shift = variant2 ? 0 : 1; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
+    ASW_TRY(launch_pack_words(ctx->stream, dL, H, W, 3, 0, pxa.as<uint32_t>()));
+    if (!variant2) ASW_TRY(launch_pack_words(ctx->stream, dR, H, W, 3, 0, pxb.as<uint32_t>()));
+    a.guideA = pxa.as<uint32_t>(); a.guideB = variant2 ? nullptr : pxb.as<uint32_t>();
     if (variant2) {
-        ASW_TRY(build_similarity_volume(ctx, dL, dR, H, W, mp.minD, n, 0.4, 10, 50, raw.as<float>()));  // M.cpp:2990
+        ASW_TRY(build_similarity_volume(ctx, dL, dR, H, W, mp.minD, n, 0.4, 10, 50, raw.as<float>(), parts.as<uint32_t>(),
+                                        psc.as<float2>()));  // M.cpp:2990 (+ the min/max of M.cpp:2775, fused)
         ASW_TRY(launch_u8_scale(ctx->stream, dL, plane * 3, ord.as<uint32_t>() + 2 * n, gsc.as<float2>()));
     } else {
         DevBuf& gl = ctx->buf("grayL");
@@ -382,10 +390,11 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
         ASW_TRY(launch_guide_scales_lr(ctx->stream, dL, dR, H, W, mp.minD, n, mp.disparity_type, ord.as<uint32_t>() + 2 * n,
                                        colmm.as<int>(), gsc.as<float2>()));
     }
-    ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));  // M.cpp:2775
+    if (!variant2)
+        ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));  // M.cpp:2775
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = n; a.r = mp.win; a.minD = mp.minD; a.eps = mp.eps;
-    a.meanI = meanI.as<float>(); a.den = den.as<float>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
+    a.stats = stats.as<float>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
@@ -746,27 +755,32 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     DevBuf& ord = ctx->buf("g_ord");
     DevBuf& psc = ctx->buf("g_pscales");
     DevBuf& gsc = ctx->buf("g_gscales");
-    DevBuf& meanI = ctx->buf("g_meanI");
-    DevBuf& den = ctx->buf("g_den");
+    DevBuf& stats = ctx->buf("g_stats");
     DevBuf& ab = ctx->buf("g_ab");
     DevBuf& qv = ctx->buf("g_q1");
+    DevBuf& pxa = ctx->buf("bgrxL");
+    DevBuf& pxb = ctx->buf("bgrxR");
     ASW_TRY(upload_image(ctx, guide, dg));
     ASW_TRY(raw.ensure(plane * 4));
     ASW_TRY(ord.ensure(4 * 4));
     ASW_TRY(psc.ensure(sizeof(float2)));
     ASW_TRY(gsc.ensure(sizeof(float2)));
-    ASW_TRY(meanI.ensure(plane * C * 4));
-    ASW_TRY(den.ensure(plane * C * 4));
-    ASW_TRY(ab.ensure(plane * (C + 1) * 4));
+    ASW_TRY(stats.ensure(guided_stats_floats(C, 1, H, W) * 4));
+    ASW_TRY(ab.ensure(guided_ab_floats(C, 1, H, W) * 4));
     ASW_TRY(qv.ensure(plane * 4));
+    ASW_TRY(pxa.ensure(plane * 4));
+    ASW_TRY(pxb.ensure(plane * 4));
+    ASW_TRY(launch_pack_words(ctx->stream, dg.as<uint8_t>(), H, W, C, 0, pxa.as<uint32_t>()));
+    if (C == 6) ASW_TRY(launch_pack_words(ctx->stream, dg.as<uint8_t>(), H, W, C, 1, pxb.as<uint32_t>()));
     ASW_HIP_TRY(hipMemcpyAsync(raw.p, p, plane * 4, hipMemcpyHostToDevice, ctx->stream));
     ASW_TRY(launch_u8_scale(ctx->stream, dg.as<uint8_t>(), plane * C, ord.as<uint32_t>() + 2, gsc.as<float2>()));  // M.cpp:2774
     ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), 1, plane, ord.as<uint32_t>(), psc.as<float2>()));     // M.cpp:2775
     GuidedLaunch a;
-    a.mode = 2; a.C = C; a.guide_per_slice = 0; a.guideA = dg.as<uint8_t>(); a.guideB = nullptr;
+    a.shift = 0; a.C = C; a.guide_per_slice = 0;
+    a.guideA = pxa.as<uint32_t>(); a.guideB = C == 6 ? pxb.as<uint32_t>() : nullptr;
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;
-    a.meanI = meanI.as<float>(); a.den = den.as<float>(); a.ab = ab.as<float>(); a.q = qv.as<float>();
+    a.stats = stats.as<float>(); a.ab = ab.as<float>(); a.q = qv.as<float>();
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_HIP_TRY(hipMemcpyAsync(q, qv.p, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -83,8 +83,12 @@ int bilateral_lds_row_stride(int win);  // LW of the kernel's sample tile (taps[
 
 // ---- cost kernels (k_cost.hip) ----
 int launch_scharr_x(hipStream_t s, const uint8_t* img, int H, int W, int pad, short* grad /* [H][W+pad][3] */);
+// ord_scratch (similarity_parts_words() u32 words) / scales (optional): fused per-slice min/max -> normalize()
+// parameters of every cost plane
+size_t similarity_parts_words(int H, int W, int numD);
 int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const short* gL, const short* gR, int H, int W,
-                      int minD, int numD, double regularity, double thresC, double thresG, float* cost);
+                      int minD, int numD, double regularity, double thresC, double thresG, float* cost, uint32_t* ord_scratch,
+                      float2* scales);
 int launch_pad_reflect(hipStream_t s, const float* src, int n, int H, int W, int h, float* dst);
 // per-slice normalize(NORM_MINMAX) parameters {scale, shift} of a dense f32 volume [n][plane]
 int launch_slice_scales(hipStream_t s, const float* vol, int n, size_t plane, uint32_t* ord_scratch /* 2n */, float2* scales);
@@ -97,20 +101,23 @@ int launch_box_filter(hipStream_t s, const float* in, float* out, int n, int H, 
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost);
 struct GuidedLaunch {
-    const uint8_t* guideA;  // mode 0/1: 3-channel reference image; mode 2: C-channel interleaved guide
-    const uint8_t* guideB;  // mode 1: the image whose disparity-shifted view forms channels 3..5
-    int mode, C;            // C = 3 or 6
+    const uint32_t* guideA; // BGRX plane holding guide channels 0..2
+    const uint32_t* guideB; // BGRX plane holding guide channels 3..5 (C = 6), else null
+    int shift;              // 1: channels 3..5 are read at reflect(x - d) (GuidedF), 0: at x
+    int C;                  // 3 or 6
     int guide_per_slice;    // 1: guide (hence its statistics and scales) changes with the slice
     const float2* gscales;  // guide normalize() parameters (1 or n entries)
     const float* P;         // raw cost volume [n][H][W]
     const float2* pscales;  // per-slice normalize() parameters of P
     int H, W, n, r, minD;
     double eps;
-    float* meanI;           // scratch [nstat][C][H][W]
-    float* den;             // scratch [nstat][C][H][W]
-    float* ab;              // scratch [n][C+1][H][W]
+    float* stats;           // scratch, guided_stats_floats(): {meanI_c, var_c+eps} interleaved per pixel
+    float* ab;              // scratch, guided_ab_floats(): {a_c, b} interleaved per pixel
     float* q;               // out [n][H][W]
 };
+size_t guided_stats_floats(int C, int nstat, int H, int W);
+size_t guided_ab_floats(int C, int n, int H, int W);
+int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, int w, uint32_t* out);
 int launch_guided(hipStream_t s, const GuidedLaunch& a);
 
 // ---- geodesic support weights (k_geodesic.hip) ----

@@ -25,6 +25,8 @@
 //    1101-1106); the right-hand weight is evaluated AT max(0,x-d) (its neighbour is clamped from
 //    there), which is why the right staging clamps explicitly.
 // This kernel is f64-VALU-bound, not HBM-bound ("Rooflines").
+#include <stdlib.h>
+
 #include "asw_internal.h"
 
 namespace {
@@ -41,13 +43,17 @@ constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / 
 
 // LDS layout as a function of the half window h (compile-time when HH > 0)
 struct Layout {
-    int h, TR, LW, LWp, RW, RWp, offC, offWR, offL, offR, total;
+    int h, TR, LW, LWp, RW, RWp, offC, offWR, offWL, offL, offR, total;
     __host__ __device__ constexpr Layout(int h_, int G)
         : h(h_), TR(TH + 2 * h_), LW(TW + 2 * h_), LWp(round_up(TW + 2 * h_, 4)), RW(TW + 2 * h_ + DCMAX - 1),
           RWp(round_up(TW + 2 * h_ + DCMAX - 1, 4)), offC(0), offWR(round_up((TH + 2 * h_) * (TW + 2 * h_) * DCMAX, 16)),
-          offL(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16)),
-          offR(offL + round_up((TH + 2 * h_) * round_up(TW + 2 * h_, 4), 16)),
-          total(offR + round_up((TH + 2 * h_) * round_up(TW + 2 * h_ + DCMAX - 1, 4), 16))
+          offWL(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16)),
+          offL(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16) + G * TH * TW * 4),
+          offR(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16) + G * TH * TW * 4 +
+               round_up((TH + 2 * h_) * round_up(TW + 2 * h_, 4), 16)),
+          total(offWR + round_up(G * TH * (TW + DCMAX - 1) * 4, 16) + G * TH * TW * 4 +
+                round_up((TH + 2 * h_) * round_up(TW + 2 * h_, 4), 16) +
+                round_up((TH + 2 * h_) * round_up(TW + 2 * h_ + DCMAX - 1, 4), 16))
     {
     }
 };
@@ -83,6 +89,7 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     uint8_t* sR = smem + lay.offR;
     uint8_t* sC = smem + lay.offC;
     float* sWR = reinterpret_cast<float*>(smem + lay.offWR);
+    float* sWL = reinterpret_cast<float*>(smem + lay.offWL);
     constexpr int SWR = TW + DC - 1;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -151,7 +158,6 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
 
     for (int g0 = 0; g0 < p.ntaps; g0 += G) {
         __syncthreads();  // previous group's weights consumed (first pass: cost tile complete)
-        float wlv[G];
 #pragma unroll
         for (int t = 0; t < G; t++) {
             const int4 tp = taps[g0 + t];  // uniform: scalar loads
@@ -168,14 +174,16 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
                     dstB[t * (TH * SWR)] = lut[__builtin_amdgcn_sad_u16(nb, ctrB, tp.w)];
                 }
             }
-            // this thread's own left-image weight (M.cpp:1062,1065)
-            wlv[t] = lut[__builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w)];
+            // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
+            sWL[t * (TH * TW) + tid] = lut[__builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w)];
         }
         __syncthreads();
-#pragma unroll
+        // rolled on purpose: one tap's operands (1 + 4 + DC registers) live at a time keeps the kernel at
+        // <= 128 VGPRs, i.e. 4 waves per SIMD, which hides the LDS latency better than deeper unrolling did
+#pragma unroll 1
         for (int t = 0; t < G; t++) {
             const int4 tp = taps[g0 + t];
-            const float wl = wlv[t];
+            const float wl = sWL[t * (TH * TW) + tid];
             uint32_t cw[(DC + 3) / 4];
             load_cost<DC>(myC + tp.x * DC, cw);
             const float* w = myWR + t * (TH * SWR);
@@ -204,8 +212,8 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     }
 }
 
-template <int HH, int G>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_asw_bilateral(
+template <int HH, int G, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_asw_bilateral(
     BilParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ taps,
     const float* __restrict__ lut, float* __restrict__ vol, float* __restrict__ disp)
 {
@@ -236,14 +244,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     if (x < W && y < H) disp[(size_t)y * W + x] = bestD;
 }
 
-template <int HH, int G>
+template <int HH, int G, int WPE = 2>
 int launch_t(hipStream_t s, const BilateralLaunch& a)
 {
     BilParams p;
     p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps;
     const Layout lay(p.h, G);
     if (lay.total > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
-    auto kern = k_asw_bilateral<HH, G>;
+    auto kern = k_asw_bilateral<HH, G, WPE>;
     if (lay.total > 64 * 1024)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total));
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH);
@@ -260,8 +268,10 @@ int bilateral_lds_row_stride(int win) { return TW + 2 * (win / 2); }
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a)
 {
     switch (a.win) {
-    case 15: return launch_t<7, 8>(s, a);   // the reference's call site (main.cpp:94) and configs C1/C5
-    case 35: return launch_t<17, 8>(s, a);  // config C2
-    default: return launch_t<0, 8>(s, a);   // any other odd window: layout computed at run time
+    // <half window, taps per staging group, waves per SIMD the register allocator must allow>.
+    // win 15, measured on MI355X (1080p, D=128): <7,8,2> 18.6 ms, <7,8,3> 15.7, <7,4,3> 16.3, <7,4,4> 14.3 ms.
+    case 15: return launch_t<7, 4, 4>(s, a);   // the reference's call site (main.cpp:94) and configs C1/C5
+    case 35: return launch_t<17, 4, 2>(s, a);  // config C2 (cost tile 60 KB: two workgroups per CU)
+    default: return launch_t<0, 4, 3>(s, a);   // any other odd window: layout computed at run time
     }
 }

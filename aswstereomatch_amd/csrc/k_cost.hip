@@ -63,48 +63,27 @@ __device__ __forceinline__ float similarity_pixel(int c0, int c1, int c2, float 
     return cc * rr + cg * rg;                           // addWeighted(cc, 1-reg, cg, reg)   (M.cpp:484)
 }
 
-// computeSimilarity, DISPARITY_LEFT + 3 channels (the only branch that can execute, App. B-7).
-// grid: (ceil(W/256), ceil(H/ROWS), numD); cost plane k <-> offset minD+k.
-constexpr int SIM_ROWS = 8;
-__global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
-                                                    const short* __restrict__ gL, const short* __restrict__ gR, int H, int W,
-                                                    int minD, int numD, float rr, float rg, float thresCf, double thresC,
-                                                    double thresG, float thresGf, float* __restrict__ cost)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = blockIdx.z, off = minD + k, max_off = minD + numD - 1, Wb = W + max_off;
-    if (x >= W) return;
-    const int cb = max_off - off + x;              // column in the padded right image (M.cpp:455)
-    const int xr = reflect_idx(cb - max_off, W);   // = reflect(x - off)
-    const int y0 = blockIdx.y * SIM_ROWS, y1 = min(H, y0 + SIM_ROWS);
-    for (int y = y0; y < y1; y++) {
-        const uint8_t* a = L + ((size_t)y * W + x) * 3;
-        const uint8_t* b = R + ((size_t)y * W + xr) * 3;
-        const short* ga = gL + ((size_t)y * W + x) * 3;
-        const short* gb = gR + ((size_t)y * Wb + cb) * 3;
-        int c0 = abs((int)a[0] - (int)b[0]), c1 = abs((int)a[1] - (int)b[1]), c2 = abs((int)a[2] - (int)b[2]);
-        float g0 = fabsf((float)ga[0] - (float)gb[0]), g1 = fabsf((float)ga[1] - (float)gb[1]),
-              g2 = fabsf((float)ga[2] - (float)gb[2]);
-        cost[((size_t)k * H + y) * W + x] = similarity_pixel(c0, c1, c2, g0, g1, g2, rr, rg, thresCf, thresC, thresG, thresGf);
-    }
-}
-
-// copyMakeBorder(plane, h,h,h,h, BORDER_REFLECT) for every plane (M.cpp:662-667)
-__global__ __launch_bounds__(256) void k_pad_reflect(const float* __restrict__ src, int H, int W, int h,
-                                                     float* __restrict__ dst)
-{
-    const int Hp = H + 2 * h, Wp = W + 2 * h;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
-    if (x >= Wp) return;
-    dst[((size_t)k * Hp + y) * Wp + x] = src[((size_t)k * H + reflect_idx(y - h, H)) * W + reflect_idx(x - h, W)];
-}
-
 // ---- min/max reductions ------------------------------------------------------------------
 // order-preserving map float -> uint so that integer atomics give float min/max (any sign)
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+// normalize(src, dst, 0, 1, NORM_MINMAX, CV_32F) parameters (App. A-10):
+// scale = (max-min > DBL_EPSILON) ? 1/(max-min) : 0; shift = -min*scale; both cast to float.
+__device__ __forceinline__ float2 minmax_scale(double smin, double smax)
+{
+    double scale = (smax - smin > 2.220446049250313e-16) ? 1.0 / (smax - smin) : 0.0;
+    double shift = 0.0 - smin * scale;
+    return make_float2((float)scale, (float)shift);
 }
 
 __device__ __forceinline__ void block_minmax_commit(uint32_t lo, uint32_t hi, uint32_t* out2)
@@ -120,16 +99,111 @@ __device__ __forceinline__ void block_minmax_commit(uint32_t lo, uint32_t hi, ui
     }
 }
 
+// computeSimilarity, DISPARITY_LEFT + 3 channels (the only branch that can execute, App. B-7).
+// grid: (ceil(W/256), ceil(H/ROWS), numD); cost plane k <-> offset minD+k.
+constexpr int SIM_ROWS = 8;
+__global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                    const short* __restrict__ gL, const short* __restrict__ gR, int H, int W,
+                                                    int minD, int numD, float rr, float rg, float thresCf, double thresC,
+                                                    double thresG, float thresGf, float* __restrict__ cost,
+                                                    uint32_t* __restrict__ parts /* optional [numD][blocks][2] min/max keys */)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.z, off = minD + k, max_off = minD + numD - 1, Wb = W + max_off;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    if (x < W) {
+    const int cb = max_off - off + x;              // column in the padded right image (M.cpp:455)
+    const int xr = reflect_idx(cb - max_off, W);   // = reflect(x - off)
+    const int y0 = blockIdx.y * SIM_ROWS, y1 = min(H, y0 + SIM_ROWS);
+    for (int y = y0; y < y1; y++) {
+        const uint8_t* a = L + ((size_t)y * W + x) * 3;
+        const uint8_t* b = R + ((size_t)y * W + xr) * 3;
+        const short* ga = gL + ((size_t)y * W + x) * 3;
+        const short* gb = gR + ((size_t)y * Wb + cb) * 3;
+        int c0 = abs((int)a[0] - (int)b[0]), c1 = abs((int)a[1] - (int)b[1]), c2 = abs((int)a[2] - (int)b[2]);
+        float g0 = fabsf((float)ga[0] - (float)gb[0]), g1 = fabsf((float)ga[1] - (float)gb[1]),
+              g2 = fabsf((float)ga[2] - (float)gb[2]);
+        float v = similarity_pixel(c0, c1, c2, g0, g1, g2, rr, rg, thresCf, thresC, thresG, thresGf);
+        cost[((size_t)k * H + y) * W + x] = v;
+        uint32_t o = f2ord(v);
+        lo = min(lo, o);
+        hi = max(hi, o);
+    }
+    }
+    // normalize(NORM_MINMAX) of this slice needs its global min/max (M.cpp:2775).  Per-block partials, reduced by
+    // k_scales_from_parts: same-address atomics from 10^5 workgroups serialise (measured: +3.3 ms per frame).
+    if (parts) {
+        __shared__ uint32_t s_lo[4], s_hi[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+            parts[((size_t)k * nb + b) * 2] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+            parts[((size_t)k * nb + b) * 2 + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        }
+    }
+}
+
+// parts[n][nb][2] -> scales[n]
+__global__ __launch_bounds__(256) void k_scales_from_parts(const uint32_t* __restrict__ parts, int nb, float2* __restrict__ scales)
+{
+    const int k = blockIdx.x;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        lo = min(lo, parts[((size_t)k * nb + i) * 2]);
+        hi = max(hi, parts[((size_t)k * nb + i) * 2 + 1]);
+    }
+    __shared__ uint32_t s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        scales[k] = minmax_scale((double)ord2f(lo), (double)ord2f(hi));
+    }
+}
+
+// copyMakeBorder(plane, h,h,h,h, BORDER_REFLECT) for every plane (M.cpp:662-667)
+__global__ __launch_bounds__(256) void k_pad_reflect(const float* __restrict__ src, int H, int W, int h,
+                                                     float* __restrict__ dst)
+{
+    const int Hp = H + 2 * h, Wp = W + 2 * h;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= Wp) return;
+    dst[((size_t)k * Hp + y) * Wp + x] = src[((size_t)k * H + reflect_idx(y - h, H)) * W + reflect_idx(x - h, W)];
+}
+
 // per-slice min/max of a dense f32 volume [n][plane] -> ord[2*n] (init: {0xffffffff, 0})
 __global__ __launch_bounds__(256) void k_slice_minmax(const float* __restrict__ vol, size_t plane, uint32_t* __restrict__ ord)
 {
     const int k = blockIdx.y;
     const float* p = vol + (size_t)k * plane;
     uint32_t lo = 0xffffffffu, hi = 0u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t o = f2ord(p[i]);
-        lo = min(lo, o);
-        hi = max(hi, o);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((plane & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane / 4; i += stride) {
+            float4 v = p4[i];
+            uint32_t a = f2ord(v.x), b = f2ord(v.y), c = f2ord(v.z), d = f2ord(v.w);
+            lo = min(min(lo, a), min(b, min(c, d)));
+            hi = max(max(hi, a), max(b, max(c, d)));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += stride) {
+            uint32_t o = f2ord(p[i]);
+            lo = min(lo, o);
+            hi = max(hi, o);
+        }
     }
     block_minmax_commit(lo, hi, ord + 2 * k);
 }
@@ -159,21 +233,6 @@ __global__ __launch_bounds__(256) void k_col_minmax_u8(const uint8_t* __restrict
     }
     colmm[2 * x] = lo;
     colmm[2 * x + 1] = hi;
-}
-
-__device__ __forceinline__ float ord2f(uint32_t o)
-{
-    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __uint_as_float(u);
-}
-
-// normalize(src, dst, 0, 1, NORM_MINMAX, CV_32F) parameters (App. A-10):
-// scale = (max-min > DBL_EPSILON) ? 1/(max-min) : 0; shift = -min*scale; both cast to float.
-__device__ __forceinline__ float2 minmax_scale(double smin, double smax)
-{
-    double scale = (smax - smin > 2.220446049250313e-16) ? 1.0 / (smax - smin) : 0.0;
-    double shift = 0.0 - smin * scale;
-    return make_float2((float)scale, (float)shift);
 }
 
 // ord[2*n] -> scales[n] (float2 {a, b})
@@ -221,15 +280,24 @@ int launch_scharr_x(hipStream_t s, const uint8_t* img, int H, int W, int pad, sh
 }
 
 int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const short* gL, const short* gR, int H, int W,
-                      int minD, int numD, double regularity, double thresC, double thresG, float* cost)
+                      int minD, int numD, double regularity, double thresC, double thresG, float* cost, uint32_t* ord_scratch,
+                      float2* scales)
 {
+
     dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, numD);
     float rr = (float)(1.0 - regularity), rg = (float)regularity;  // regularityR, M.cpp:435
     float thresCf = (float)(thresC * (1.0 / 255.0));
     hipLaunchKernelGGL(k_similarity, grid, dim3(256), 0, s, L, R, gL, gR, H, W, minD, numD, rr, rg, thresCf, thresC, thresG,
-                       (float)thresG, cost);
+                       (float)thresG, cost, ord_scratch);
+    if (ord_scratch && scales)
+        hipLaunchKernelGGL(k_scales_from_parts, dim3(numD), dim3(256), 0, s, ord_scratch, (int)(grid.x * grid.y), scales);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
+}
+
+size_t similarity_parts_words(int H, int W, int numD)
+{
+    return (size_t)2 * numD * ((W + 255) / 256) * ((H + SIM_ROWS - 1) / SIM_ROWS);
 }
 
 int launch_pad_reflect(hipStream_t s, const float* src, int n, int H, int W, int h, float* dst)
@@ -244,7 +312,7 @@ int launch_slice_scales(hipStream_t s, const float* vol, int n, size_t plane, ui
 {
     hipLaunchKernelGGL(k_fill_u32, dim3((2 * n + 255) / 256), dim3(256), 0, s, ord_scratch, 2 * n, 0xffffffffu, 0u);
     int bx = (int)((plane + 256 * 16 - 1) / (256 * 16));
-    if (bx > 256) bx = 256;
+    if (bx > 64) bx = 64;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_slice_minmax, dim3(bx, n), dim3(256), 0, s, vol, plane, ord_scratch);
     hipLaunchKernelGGL(k_scales_from_ord, dim3((n + 255) / 256), dim3(256), 0, s, ord_scratch, n, scales);

@@ -2,16 +2,17 @@
 //
 // boxFilter(CV_32F, Size(k,k), normalised, BORDER_REFLECT_101) == f64 window sum * 1/(k*k) -> f32
 // (SURVEY App. A-9).  One generic "column walk" kernel evaluates NP box means at once:
-//   * a 256-thread block owns 256 input columns (256-(k-1) output columns) of a band of rows and walks
-//     down the band; every thread keeps NP vertical running sums in f64 (add the entering row, subtract
-//     the leaving one -- the same sliding form as OpenCV's ColumnSum), the leaving row's values come
-//     from a per-thread ring in LDS (or are recomputed when the ring would not fit);
-//   * per output row the vertical sums go through LDS (double-buffered, one barrier per row) and each
+//   * a wavefront owns 64 input columns (64-(k-1) output columns) of a band of rows and walks down the
+//     band; every lane keeps NP vertical running sums in f64 (add the entering row, subtract the leaving
+//     one -- the same sliding form as OpenCV's ColumnSum; the leaving row is recomputed from cached loads);
+//   * per output row the vertical sums go through a wave-private LDS strip (no workgroup barrier) and each
 //     output column adds its k neighbours in ascending order (conflict-free ds_read_b64);
 //   * the producer (Src) and consumer (Dst) are functors, so normalisation, products, covariance,
 //     a = cov/(var+eps), b and q are fused into the filters that need them and never hit HBM as
 //     separate planes.
 // The kernels are bound by f64 VALU + HBM streaming of the a/b planes, see DESIGN.md.
+#include <stdlib.h>
+
 #include "asw_internal.h"
 
 namespace {
@@ -29,124 +30,202 @@ __device__ __forceinline__ int reflect101_idx(int p, int len)
     return p;
 }
 
-constexpr int BW = 256;  // block width = input columns per block
+constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 
-template <int NP, class Src, class Dst>
-__global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int use_ring)
+// Every wavefront owns a strip of 128 input columns (two adjacent ones per lane, 128-(k-1) output columns)
+// of a band of rows and walks down the band on its own:
+//   * vertical running sums in f64 registers (add the entering row, subtract the leaving one -- ColumnSum's
+//     sliding form; the leaving row is re-fetched from cache rather than kept: an LDS ring cost 61 KB per
+//     workgroup and 2x the run time);
+//   * the operands of step s+1 (Src::fetch / Dst::fetch: loads only) are issued before the arithmetic of
+//     step s, so their latency hides behind it;
+//   * horizontal sums through a wave-private LDS strip: LDS operations of one wavefront execute in order, so
+//     no workgroup barrier is needed; a lane's second column reuses the first one's sum (- b[0] + b[k]).
+template <int NP, int CPL, bool PF, class Src, class Dst>
+__global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw)
 {
+    constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
-    double* hs = reinterpret_cast<double*>(smem);                               // [2][NP][BW]
-    float* ring = reinterpret_cast<float*>(smem + (size_t)2 * NP * BW * sizeof(double));  // [k][BW][NP]
-    const int t = threadIdx.x, kz = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kz = blockIdx.z;
+    double* hs = reinterpret_cast<double*>(smem) + (size_t)wv * NP * (SW + 2);  // [NP][SW+2] per wavefront
     const int hl = k / 2;  // OpenCV anchor = k/2 (also for even k)
-    const int XO = BW - (k - 1);
-    const int xo0 = blockIdx.x * XO;
-    const int xin = reflect101_idx(xo0 - hl + t, W);
+    const int XO = SW - (k - 1);
+    const int xw = blockIdx.x * 4 + wv;  // wavefront's strip index
+    if (xw >= nxw) return;               // whole wavefront exits
+    const int xo0 = xw * XO;
+    const int c0 = CPL * lane;           // first strip column of this lane
+    int xin[CPL];
+    bool out_col[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        xin[c] = reflect101_idx(xo0 - hl + c0 + c, W);
+        out_col[c] = (c0 + c < XO) && (xo0 + c0 + c < W);
+    }
+    const bool any_out = out_col[0];  // columns are adjacent: column 1 is an output only if column 0 is
     const int y0 = blockIdx.y * band, y1 = min(H, y0 + band);
     const double scale = 1.0 / ((double)k * (double)k);
-    const bool out_thread = (t < XO) && (xo0 + t < W);
-    double vs[NP];
+    double vs[CPL][NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) vs[p] = 0.0;
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) vs[c][p] = 0.0;
 
     const int steps = (y1 - y0) + k - 1;
+    typename Src::Raw rn[CPL], ro[CPL];
+    typename Dst::Raw rd[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        rn[c] = src.fetch(reflect101_idx(y0 - hl, H), xin[c], kz);
+        ro[c] = rn[c];
+        rd[c] = dst.fetch(y0, min(xo0 + c0 + c, W - 1), kz);
+    }
     for (int s = 0; s < steps; s++) {
-        const int yy = reflect101_idx(y0 - hl + s, H);
-        float v[NP];
-        src(yy, xin, kz, v);
-        float* slot = ring + ((size_t)(s % k) * BW + t) * NP;
-        if (s >= k) {  // the row leaving the window (ColumnSum: SUM -= Sm)
-            float o[NP];
-            if (use_ring) {
+        if (!PF && s > 0) {  // no prefetch: fetch this step's operands now
+            const int yn = reflect101_idx(y0 - hl + s, H);
+            const int yo = reflect101_idx(y0 - hl + s - k, H);
+            const int yd = min(max(y0 + s - (k - 1), y0), y1 - 1);
 #pragma unroll
-                for (int p = 0; p < NP; p++) o[p] = slot[p];
-            } else {
-                src(reflect101_idx(y0 - hl + s - k, H), xin, kz, o);
+            for (int c = 0; c < CPL; c++) {
+                rn[c] = src.fetch(yn, xin[c], kz);
+                if (s >= k) ro[c] = src.fetch(yo, xin[c], kz);
+                if (s >= k - 1) rd[c] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz);
             }
-#pragma unroll
-            for (int p = 0; p < NP; p++) vs[p] = vs[p] - (double)o[p];
         }
+        // ---- consume the operands fetched one step ago ----
 #pragma unroll
-        for (int p = 0; p < NP; p++) vs[p] = vs[p] + (double)v[p];
-        if (use_ring) {
+        for (int c = 0; c < CPL; c++) {
+            if (s >= k) {  // the row leaving the window (ColumnSum: SUM -= Sm)
+                float o[NP];
+                src.eval(ro[c], kz, o);
 #pragma unroll
-            for (int p = 0; p < NP; p++) slot[p] = v[p];
+                for (int p = 0; p < NP; p++) vs[c][p] = vs[c][p] - (double)o[p];
+            }
+            float v[NP];
+            src.eval(rn[c], kz, v);
+#pragma unroll
+            for (int p = 0; p < NP; p++) vs[c][p] = vs[c][p] + (double)v[p];
+        }
+        typename Dst::Raw rdc[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) rdc[c] = rd[c];
+        // ---- issue the loads of step s+1 (PF) ----
+        if (PF && s + 1 < steps) {
+            const int yn = reflect101_idx(y0 - hl + s + 1, H);
+            const int yo = reflect101_idx(y0 - hl + s + 1 - k, H);
+            const int yd = min(max(y0 + s + 1 - (k - 1), y0), y1 - 1);
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                rn[c] = src.fetch(yn, xin[c], kz);
+                if (s + 1 >= k) ro[c] = src.fetch(yo, xin[c], kz);
+                if (s + 1 >= k - 1) rd[c] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz);
+            }
         }
         if (s >= k - 1) {
-            double* buf = hs + (size_t)(s & 1) * NP * BW;
 #pragma unroll
-            for (int p = 0; p < NP; p++) buf[p * BW + t] = vs[p];
-            __syncthreads();
-            if (out_thread) {
-                float m[NP];
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) hs[p * (SW + 2) + c0 + c] = vs[c][p];
+            // same-wavefront LDS traffic is ordered: the reads below see the writes above
+            if (any_out) {
+                float m[CPL][NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
-                    const double* b = buf + p * BW + t;
+                    const double* b = hs + p * (SW + 2) + c0;
                     double sum = 0.0;
                     for (int i = 0; i < k; i++) sum = sum + b[i];
-                    m[p] = (float)(sum * scale);
+                    m[0][p] = (float)(sum * scale);
+                    if constexpr (CPL > 1) {
+                        double sum1 = (sum - b[0]) + b[k];  // window of the adjacent column
+                        m[CPL - 1][p] = (float)(sum1 * scale);
+                    }
                 }
-                dst(y0 + s - (k - 1), xo0 + t, kz, m);
+                const int y = y0 + s - (k - 1);
+                dst.emit(y, xo0 + c0, kz, rdc[0], m[0]);
+                if constexpr (CPL > 1) {
+                    if (out_col[CPL - 1]) dst.emit(y, xo0 + c0 + 1, kz, rdc[CPL - 1], m[CPL - 1]);
+                }
             }
         }
     }
 }
 
 // ---- guide access: normalised guide channels I_c(y,x) for slice k --------------------------------
-// mode 0: 3 channels from A.  mode 1: channels 0-2 from A, 3-5 from B shifted by the slice's disparity
-// through the REFLECT pad (M.cpp:2907-2912).  mode 2: C interleaved channels in A (public getGuidedFilter).
+// The guide lives in packed BGRX planes (one dword per pixel): channels 0-2 from A at x; channels 3-5 from B
+// at x (shift = 0: 6-channel guide of the public getGuidedFilter) or at reflect(x - d) (shift = 1: the
+// disparity-shifted right image of computeAdaptiveWeight_GuidedF, M.cpp:2907-2912).
 struct GuideAcc {
-    const uint8_t* A;
-    const uint8_t* B;
+    const uint32_t* A;
+    const uint32_t* B;
     const float2* scales;  // normalize() scale/shift per slice (index k * scale_stride)
     int scale_stride;
-    int W, mode, minD, C;
-    template <int C0, int N>
-    __device__ __forceinline__ void load(int y, int x, int k, float (&I)[N]) const
+    int W, shift, minD;
+    template <int NW>
+    __device__ __forceinline__ void fetch(int y, int x, int k, uint32_t (&u)[NW]) const
+    {
+        u[0] = A[(size_t)y * W + x];
+        if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shift ? reflect_idx(x - (minD + k), W) : x)];
+    }
+    template <int NW>
+    __device__ __forceinline__ void eval(const uint32_t (&u)[NW], int k, float (&I)[3 * NW]) const
     {
         const float2 sc = scales[k * scale_stride];
 #pragma unroll
-        for (int c = 0; c < N; c++) {
-            const int ch = C0 + c;
-            int u;
-            if (mode == 2) u = A[((size_t)y * W + x) * C + ch];
-            else if (ch < 3) u = A[((size_t)y * W + x) * 3 + ch];
-            else u = B[((size_t)y * W + reflect_idx(x - (minD + k), W)) * 3 + (ch - 3)];
-            I[c] = (float)u * sc.x + sc.y;  // convertTo 8u->32f with float scale/shift (App. A-10)
+        for (int w = 0; w < NW; w++) {
+            // convertTo 8u->32f with float scale/shift (App. A-10): v_cvt_f32_ubyteN, mul, add
+            I[3 * w + 0] = (float)(u[w] & 0xffu) * sc.x + sc.y;
+            I[3 * w + 1] = (float)((u[w] >> 8) & 0xffu) * sc.x + sc.y;
+            I[3 * w + 2] = (float)((u[w] >> 16) & 0xffu) * sc.x + sc.y;
         }
     }
 };
 
+struct NoRaw {};
+
+// Guide statistics, interleaved per pixel: stats[kslot][y][x][SS] = {meanI_0..C-1, den_0..C-1, pad} with
+// SS = 8 (C=3) or 12 (C=6) floats, so the consumer fetches them with 2-3 dwordx4 loads.
+template <int C> struct StatStride { static constexpr int value = (C == 3) ? 8 : 12; };
+
 // box(I_c), box(I_c*I_c) -> meanI_c, den_c = (corrI_c - meanI_c^2) + eps      (M.cpp:2778, 2796-2799, 2846)
-template <int C0>
+template <int C, int W0>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
 struct StatsSrc {
     GuideAcc g;
-    __device__ __forceinline__ void operator()(int y, int x, int k, float (&v)[6]) const
+    struct Raw { uint32_t u[C / 3]; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
-        float I[3];
-        g.template load<C0, 3>(y, x, k, I);
+        Raw r;
+        g.template fetch<C / 3>(y, x, k, r.u);
+        return r;
+    }
+    __device__ __forceinline__ void eval(const Raw& r, int k, float (&v)[6]) const
+    {
+        float I[C];
+        g.template eval<C / 3>(r.u, k, I);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { v[c] = I[c]; v[3 + c] = I[c] * I[c]; }
+        for (int c = 0; c < 3; c++) { v[c] = I[3 * W0 + c]; v[3 + c] = I[3 * W0 + c] * I[3 * W0 + c]; }
     }
 };
-template <int C0>
+template <int C, int W0>
 struct StatsDst {
-    float* meanI;  // [kslot][C][H][W]
-    float* den;
-    int H, W, C;
+    float* stats;
+    int H, W;
     float epsf;
-    __device__ __forceinline__ void operator()(int y, int x, int k, const float (&m)[6]) const
+    typedef NoRaw Raw;
+    __device__ __forceinline__ Raw fetch(int, int, int) const { return Raw(); }
+    __device__ __forceinline__ void emit(int y, int x, int k, const Raw&, const float (&m)[6]) const
     {
+        float* o = stats + (((size_t)k * H + y) * W + x) * StatStride<C>::value;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            size_t o = (((size_t)k * C + C0 + c) * H + y) * W + x;
             float mm = m[c] * m[c];
             float var = m[3 + c] - mm;
-            meanI[o] = m[c];
-            den[o] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
+            o[3 * W0 + c] = m[c];
+            o[C + 3 * W0 + c] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
         }
     }
 };
+
+// a/b planes interleaved per pixel: ab[k][y][x][AS], AS = 4 (C=3) or 8 (C=6): {a_0..a_C-1, b, pad}
+template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
 
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
 template <int C>
@@ -155,12 +234,20 @@ struct ABSrc {
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
     int H, W;
-    __device__ __forceinline__ void operator()(int y, int x, int k, float (&v)[C + 1]) const
+    struct Raw { uint32_t u[C / 3]; float p; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    {
+        Raw r;
+        g.template fetch<C / 3>(y, x, k, r.u);
+        r.p = P[((size_t)k * H + y) * W + x];
+        return r;
+    }
+    __device__ __forceinline__ void eval(const Raw& r, int k, float (&v)[C + 1]) const
     {
         float I[C];
-        g.template load<0, C>(y, x, k, I);
+        g.template eval<C / 3>(r.u, k, I);
         const float2 sc = pscales[k];
-        float p = P[((size_t)k * H + y) * W + x] * sc.x + sc.y;
+        float p = r.p * sc.x + sc.y;
         v[0] = p;
 #pragma unroll
         for (int c = 0; c < C; c++) v[1 + c] = I[c] * p;
@@ -168,27 +255,43 @@ struct ABSrc {
 };
 template <int C>
 struct ABDst {
-    const float* meanI;
-    const float* den;
-    float* ab;  // [n][C+1][H][W]
+    const float* stats;
+    float* ab;
     int H, W, stat_stride;  // stat_stride: 1 when the guide statistics depend on the slice, else 0
-    __device__ __forceinline__ void operator()(int y, int x, int k, const float (&m)[C + 1]) const
+    static constexpr int SS = StatStride<C>::value, AS = ABStride<C>::value;
+    struct Raw { float4 s[SS / 4]; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
+        Raw r;
+        const float4* p = reinterpret_cast<const float4*>(stats + (((size_t)(k * stat_stride) * H + y) * W + x) * SS);
+#pragma unroll
+        for (int i = 0; i < SS / 4; i++) r.s[i] = p[i];
+        return r;
+    }
+    __device__ __forceinline__ void emit(int y, int x, int k, const Raw& r, const float (&m)[C + 1]) const
+    {
+        float st[SS];
+#pragma unroll
+        for (int i = 0; i < SS / 4; i++) { st[4 * i] = r.s[i].x; st[4 * i + 1] = r.s[i].y; st[4 * i + 2] = r.s[i].z; st[4 * i + 3] = r.s[i].w; }
         const float meanP = m[0];
         float dot = 0.0f;
-        const int ks = k * stat_stride;
+        float o[AS];
+#pragma unroll
+        for (int i = 0; i < AS; i++) o[i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            size_t so = (((size_t)ks * C + c) * H + y) * W + x;
-            float mI = meanI[so];
+            float mI = st[c];
             float mp = mI * meanP;
             float cov = m[1 + c] - mp;
-            float ac = cov / den[so];
-            ab[(((size_t)k * (C + 1) + c) * H + y) * W + x] = ac;
+            float ac = cov / st[C + c];
+            o[c] = ac;
             float pr = ac * mI;
             dot = (c == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
         }
-        ab[(((size_t)k * (C + 1) + C) * H + y) * W + x] = meanP - dot;
+        o[C] = meanP - dot;
+        float4* dstp = reinterpret_cast<float4*>(ab + (((size_t)k * H + y) * W + x) * AS);
+#pragma unroll
+        for (int i = 0; i < AS / 4; i++) dstp[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
     }
 };
 
@@ -197,10 +300,23 @@ template <int C>
 struct QSrc {
     const float* ab;
     int H, W;
-    __device__ __forceinline__ void operator()(int y, int x, int k, float (&v)[C + 1]) const
+    static constexpr int AS = ABStride<C>::value;
+    struct Raw { float4 v[AS / 4]; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
+        Raw r;
+        const float4* p = reinterpret_cast<const float4*>(ab + (((size_t)k * H + y) * W + x) * AS);
 #pragma unroll
-        for (int c = 0; c < C + 1; c++) v[c] = ab[(((size_t)k * (C + 1) + c) * H + y) * W + x];
+        for (int i = 0; i < AS / 4; i++) r.v[i] = p[i];
+        return r;
+    }
+    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[C + 1]) const
+    {
+        float t[AS];
+#pragma unroll
+        for (int i = 0; i < AS / 4; i++) { t[4 * i] = r.v[i].x; t[4 * i + 1] = r.v[i].y; t[4 * i + 2] = r.v[i].z; t[4 * i + 3] = r.v[i].w; }
+#pragma unroll
+        for (int c = 0; c < C + 1; c++) v[c] = t[c];
     }
 };
 template <int C>
@@ -208,10 +324,17 @@ struct QDst {
     GuideAcc g;
     float* q;  // [n][H][W]
     int H, W;
-    __device__ __forceinline__ void operator()(int y, int x, int k, const float (&m)[C + 1]) const
+    struct Raw { uint32_t u[C / 3]; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    {
+        Raw r;
+        g.template fetch<C / 3>(y, x, k, r.u);
+        return r;
+    }
+    __device__ __forceinline__ void emit(int y, int x, int k, const Raw& r, const float (&m)[C + 1]) const
     {
         float I[C];
-        g.template load<0, C>(y, x, k, I);
+        g.template eval<C / 3>(r.u, k, I);
         float dot = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -227,24 +350,28 @@ struct SadSrc {
     const uint8_t* gl;
     const uint8_t* gr;
     int W, minD, disp_type;
-    __device__ __forceinline__ void operator()(int y, int x, int k, float (&v)[1]) const
+    struct Raw { int a, b; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
         const int d = minD + k;
-        int a, b;
+        Raw r;
         if (disp_type == ASW_DISPARITY_LEFT) {
-            a = gl[(size_t)y * W + x];
-            b = gr[(size_t)y * W + reflect_idx(x - d, W)];
+            r.a = gl[(size_t)y * W + x];
+            r.b = gr[(size_t)y * W + reflect_idx(x - d, W)];
         } else {
-            a = gl[(size_t)y * W + reflect_idx(x + d, W)];
-            b = gr[(size_t)y * W + x];
+            r.a = gl[(size_t)y * W + reflect_idx(x + d, W)];
+            r.b = gr[(size_t)y * W + x];
         }
-        v[0] = (float)abs(a - b);
+        return r;
     }
+    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)abs(r.a - r.b); }
 };
 struct PlaneDst {
     float* out;
     int H, W;
-    __device__ __forceinline__ void operator()(int y, int x, int k, const float (&m)[1]) const
+    typedef NoRaw Raw;
+    __device__ __forceinline__ Raw fetch(int, int, int) const { return Raw(); }
+    __device__ __forceinline__ void emit(int y, int x, int k, const Raw&, const float (&m)[1]) const
     {
         out[((size_t)k * H + y) * W + x] = m[0];
     }
@@ -252,34 +379,36 @@ struct PlaneDst {
 struct PlaneSrc {
     const float* in;
     int H, W;
-    __device__ __forceinline__ void operator()(int y, int x, int k, float (&v)[1]) const
-    {
-        v[0] = in[((size_t)k * H + y) * W + x];
-    }
+    struct Raw { float v; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int k) const { return Raw{in[((size_t)k * H + y) * W + x]}; }
+    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = r.v; }
 };
+
+template <int NP, int CPL, bool PF, class Src, class Dst>
+int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
+{
+    constexpr int SW = 64 * CPL;
+    if (k < 1 || k > SW / 2) return ASW_ERR_BAD_ARGUMENT;  // k-1 halo columns must leave outputs in the strip
+    const int XO = SW - (k - 1);
+    const int nxw = (W + XO - 1) / XO;
+    int band = 64;
+    if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
+    size_t lds = (size_t)4 * NP * (SW + 2) * sizeof(double);
+    auto kern = k_box_walk<NP, CPL, PF, Src, Dst>;
+    dim3 grid((nxw + 3) / 4, (H + band - 1) / band, n);
+    hipLaunchKernelGGL(kern, grid, dim3(BW), lds, s, src, dst, H, W, k, band, nxw);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
 
 template <int NP, class Src, class Dst>
 int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
 {
-    if (k < 1 || k > BW - 32) return ASW_ERR_BAD_ARGUMENT;
-    const int XO = BW - (k - 1);
-    int band = 64;
-    if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
-    size_t hs_bytes = (size_t)2 * NP * BW * sizeof(double);
-    size_t ring_bytes = (size_t)k * BW * NP * sizeof(float);
-    int use_ring = (hs_bytes + ring_bytes <= 64 * 1024) ? 1 : 0;
-    auto kern = k_box_walk<NP, Src, Dst>;
-    size_t lds = hs_bytes + (use_ring ? ring_bytes : 0);
-    if (!use_ring && hs_bytes + ring_bytes <= 150 * 1024) {
-        // a bigger ring still beats recomputing the leaving row; ask for the larger LDS carve-out
-        use_ring = 1;
-        lds = hs_bytes + ring_bytes;
-        ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    dim3 grid((W + XO - 1) / XO, (H + band - 1) / band, n);
-    hipLaunchKernelGGL(kern, grid, dim3(BW), lds, s, src, dst, H, W, k, band, use_ring);
-    ASW_HIP_TRY(hipGetLastError());
-    return ASW_OK;
+    // Measured on MI355X (1080p D=128): <CPL,PF> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
+    // pair of launches; 24.3 / 24.9 / 24.3 / 24.1 ms for NP=7.  The kernels are bound by the memory system
+    // (L2/MALL re-reads of statistics and a/b planes), not by issue: prefetching buys nothing, two adjacent
+    // columns per lane save the shared horizontal sum.
+    return launch_walk_t<NP, 2, false>(s, src, dst, H, W, k, n);
 }
 
 }  // namespace
@@ -303,35 +432,34 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
 {
     GuideAcc g;
     g.A = a.guideA; g.B = a.guideB; g.scales = a.gscales; g.scale_stride = a.guide_per_slice ? 1 : 0;
-    g.W = a.W; g.mode = a.mode; g.minD = a.minD; g.C = a.C;
+    g.W = a.W; g.shift = a.shift; g.minD = a.minD;
     const int nstat = a.guide_per_slice ? a.n : 1;
     const float epsf = (float)a.eps;
     int rc;
-    // 1. guide statistics: meanI_c, den_c (once when the guide does not depend on the slice)
-    {
-        StatsSrc<0> src{g};
-        StatsDst<0> dst{a.meanI, a.den, a.H, a.W, a.C, epsf};
-        rc = launch_walk<6>(s, src, dst, a.H, a.W, a.r, nstat);
-        if (rc != ASW_OK) return rc;
-        if (a.C == 6) {
-            StatsSrc<3> src2{g};
-            StatsDst<3> dst2{a.meanI, a.den, a.H, a.W, a.C, epsf};
-            rc = launch_walk<6>(s, src2, dst2, a.H, a.W, a.r, nstat);
-            if (rc != ASW_OK) return rc;
-        }
-    }
-    // 2. a, b    3. q
     if (a.C == 3) {
+        // 1. guide statistics (once: the guide does not depend on the slice)  2. a, b  3. q
+        StatsSrc<3, 0> ss{g};
+        StatsDst<3, 0> sd{a.stats, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
         ABSrc<3> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3> dst{a.meanI, a.den, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
+        ABDst<3> dst{a.stats, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
         rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
         QDst<3> qd{g, a.q, a.H, a.W};
         return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
     } else {
+        StatsSrc<6, 0> s0{g};
+        StatsDst<6, 0> d0{a.stats, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, s0, d0, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
+        StatsSrc<6, 1> s1{g};
+        StatsDst<6, 1> d1{a.stats, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, s1, d1, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
         ABSrc<6> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<6> dst{a.meanI, a.den, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
+        ABDst<6> dst{a.stats, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
         rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<6> qs{a.ab, a.H, a.W};
@@ -339,3 +467,25 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         return launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);
     }
 }
+
+// interleaved C-channel 8U image -> BGRX word planes (channels 3w..3w+2 in plane w)
+namespace {
+__global__ __launch_bounds__(256) void k_pack_words(const uint8_t* __restrict__ img, size_t n, int C, int w, uint32_t* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = img + i * C + 3 * w;
+    out[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+}  // namespace
+
+int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, int w, uint32_t* out)
+{
+    size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(k_pack_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, n, C, w, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+size_t guided_stats_floats(int C, int nstat, int H, int W) { return (size_t)nstat * H * W * (C == 3 ? 8 : 12); }
+size_t guided_ab_floats(int C, int n, int H, int W) { return (size_t)n * H * W * (C == 3 ? 4 : 8); }
