@@ -159,9 +159,10 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     const int win = p.win, h = win / 2, H = p.H, W = p.W;
     const int TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
     constexpr int SWR = TW + DC - 1;
-    // LDS carve-up (sized on the host for DC = GDC)
-    float* sC = reinterpret_cast<float*>(smem);                                  // [TR*LW][DC]
-    float* sWR = sC + (size_t)TR * LW * GDC;                                     // [GG][TH][TW+GDC-1]
+    // LDS carve-up (sized on the host for DC = GDC).  The colour-L1 cost (<= 765) is kept as u16: 16 B per cell
+    // at DC = 8 -> one ds_read_b128 per tap, and the whole workgroup needs 40 KB -> four workgroups per CU.
+    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);                            // [TR*LW][DC]
+    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);     // [GG][TH][TW+GDC-1]
     uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));  // [TR][LW]
     uint32_t* sR = sL + TR * LW;                                                 // [TR][RWmax]
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
         for (int dd = 0; dd < DC; dd++) {
             int xr = max(0, nx - (d0 + dd));
             int tc = min(max(xr - sRx0, 0), RW - 1);  // tile is clamp-replicated
-            sC[(size_t)i * DC + dd] = (float)cdist(pl, sR[r * RWmax + tc]);
+            sC[(size_t)i * DC + dd] = (uint16_t)cdist(pl, sR[r * RWmax + tc]);
         }
     }
 
@@ -197,33 +198,50 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     const int x = x0 + tx, y = y0 + ty;
     const int xc = min(x, W - 1), yc = min(y, H - 1);
     const uint16_t* myWL = wL + (size_t)yc * W + xc;
+    const uint16_t* myC = sC + (size_t)(ty * LW + tx) * DC;
+    const float* myWR = sWR + ty * (TW + GDC - 1) + tx + (DC - 1);
     const int ntaps = win * win;
 
+    int j = 0, i = 0;  // window row / column of tap t (M.cpp:1481-1483), advanced without divisions
     for (int g0 = 0; g0 < ntaps; g0 += GG) {
         const int ng = min(GG, ntaps - g0);
         __syncthreads();
-        // right-image weights of the tile rows for xr = max(0, x - d): j = tx + (DC-1) - dd
-        for (int i = tid; i < ng * TH * SWR; i += 256) {
-            int tt = i / (TH * SWR), rem = i - tt * (TH * SWR);
-            int row = rem / SWR, j = rem - row * SWR;
-            int xr = min(max(x0 - d0 - (DC - 1) + j, 0), W - 1);
+        // right-image weights of the tile rows for xr = max(0, x - d): column jj = tx + (DC-1) - dd
+        for (int q = tid; q < ng * TH * SWR; q += 256) {
+            int tt = q / (TH * SWR), rem = q - tt * (TH * SWR);
+            int row = rem / SWR, jj = rem - row * SWR;
+            int xr = min(max(x0 - d0 - (DC - 1) + jj, 0), W - 1);
             int yy = min(y0 + row, H - 1);
-            sWR[(tt * TH + row) * (TW + GDC - 1) + j] = (float)wR[(size_t)(g0 + tt) * plane + (size_t)yy * W + xr];
+            sWR[(tt * TH + row) * (TW + GDC - 1) + jj] = (float)wR[(size_t)(g0 + tt) * plane + (size_t)yy * W + xr];
         }
+        float wl_next = (float)myWL[(size_t)g0 * plane];
         __syncthreads();
         for (int tt = 0; tt < ng; tt++) {
-            const int t = g0 + tt;
-            const int j = t / win, i = t - j * win;  // window row j, column i (M.cpp:1481-1483)
-            const float wl = (float)myWL[(size_t)t * plane];
-            const float* cell = sC + (size_t)((ty + j) * LW + (tx + i)) * DC;
-            const float* wr = sWR + (tt * TH + ty) * (TW + GDC - 1) + tx + (DC - 1);
+            const float wl = wl_next;
+            if (g0 + tt + 1 < ntaps) wl_next = (float)myWL[(size_t)(g0 + tt + 1) * plane];  // next tap's weight in flight
+            const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
+            uint32_t cw[(DC + 1) / 2];
+            if constexpr (DC == 8) {
+                uint4 v = *reinterpret_cast<const uint4*>(cell);
+                cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+            } else if constexpr (DC == 4) {
+                uint2 v = *reinterpret_cast<const uint2*>(cell);
+                cw[0] = v.x; cw[1] = v.y;
+            } else if constexpr (DC == 2) {
+                cw[0] = *reinterpret_cast<const uint32_t*>(cell);
+            } else {
+                cw[0] = cell[0];
+            }
+            const float* wr = myWR + tt * TH * (TW + GDC - 1);
 #pragma unroll
             for (int dd = 0; dd < DC; dd++) {
+                float c = (float)((cw[dd >> 1] >> (16 * (dd & 1))) & 0xffffu);
                 float ab = wl * wr[-dd];   // f32
-                float abc = ab * cell[dd]; // f32 (M.cpp:1488-1490)
+                float abc = ab * c;        // f32 (M.cpp:1488-1490)
                 num[dd] = num[dd] + (double)abc;
                 den[dd] = den[dd] + (double)ab;
             }
+            if (++i == win) { i = 0; j++; }
         }
     }
     if (x < W && y < H) {
@@ -236,15 +254,14 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     }
 }
 
-__global__ __launch_bounds__(256) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
                                                       const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
                                                       const uint16_t* __restrict__ wR, float* __restrict__ vol,
                                                       float* __restrict__ disp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int h = p.win / 2, TR = TH + 2 * h, LW = TW + 2 * h;
-    float* sC = reinterpret_cast<float*>(smem);
-    float* sWR = sC + (size_t)TR * LW * GDC;
+    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);
     uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));
     const int tid = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     for (int i = tid; i < TR * LW; i += 256) {
@@ -319,7 +336,7 @@ int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* img
 {
     GeoParams p{H, W, win, minD, nD};
     const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
-    size_t lds = (size_t)TR * LW * GDC * 4 + (size_t)GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
+    size_t lds = (size_t)TR * LW * GDC * 2 + (size_t)GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
     if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     if (lds > 64 * 1024)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_asw_geodesic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
