@@ -221,10 +221,12 @@ extern "C" int asw_download_volume(asw_ctx* ctx, int slot, float* out, size_t n_
 // classic bilateral ASW: host-side tables (tap list with the reference's two index conventions,
 // weight LUT with the reference's expression) -- M.cpp:1044-1066, 1088-1102, SURVEY App. B-2
 // ------------------------------------------------------------------------------------------
-static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double gamma_g)
+// mirror = 1: table for the x-mirrored problem (DISPARITY_RIGHT runs as DISPARITY_LEFT on mirrored, swapped images:
+// M.cpp:1134-1138 is M.cpp:1104-1108 under x -> W-1-x), i.e. every x direction negated, tap ORDER unchanged.
+static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double gamma_g, int mirror)
 {
     BilateralTables& t = ctx->bil;
-    if (t.win == win && t.gamma_c == gamma_c && t.gamma_g == gamma_g && t.taps.p) return ASW_OK;
+    if (t.win == win && t.gamma_c == gamma_c && t.gamma_g == gamma_g && t.mirror == mirror && t.taps.p) return ASW_OK;
     const int ks = win, h = ks / 2, nt = ks * ks - 1;
     std::vector<int> dxw(nt), dyw(nt), dxs(nt), dys(nt);
     int n = 0;
@@ -258,8 +260,9 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double
     std::vector<int4> taps(nt);
     const int LW = bilateral_lds_row_stride(win);  // row stride of the kernel's LDS sample tile
     for (int i = 0; i < nt; i++) {
-        taps[i].x = dys[i] * LW + dxs[i];  // sample cell, consume order (transposed, App. B-2)
-        taps[i].y = dxw[i];                // weight direction, build order
+        const int sx = mirror ? -1 : 1;
+        taps[i].x = dys[i] * LW + sx * dxs[i];  // sample cell, consume order (transposed, App. B-2)
+        taps[i].y = sx * dxw[i];                // weight direction, build order
         taps[i].z = dyw[i];
         taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256;
     }
@@ -268,7 +271,7 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double
     ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
-    t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.ntaps = nt; t.ncls = (int)r2s.size();
+    t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.mirror = mirror; t.ntaps = nt; t.ncls = (int)r2s.size();
     return ASW_OK;
 }
 
@@ -283,10 +286,11 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
 {
     if (mp.win % 2 == 0 || mp.win < 3) return ASW_ERR_EVEN_WINDOW;
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;  // cvtColor(BGR2GRAY) asserts scn==3/4
-    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;  // RIGHT: next row
+    if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    const int flip = mp.disparity_type == ASW_DISPARITY_RIGHT ? 1 : 0;
     if (mp.win > 127) return ASW_ERR_BAD_ARGUMENT;
     const int H = f->rows, W = f->cols, nD = mp.numD + 1;  // inclusive range, M.cpp:1021,1074
-    ASW_TRY(ensure_bilateral_tables(ctx, mp.win, mp.gamma_c, mp.gamma_g));
+    ASW_TRY(ensure_bilateral_tables(ctx, mp.win, mp.gamma_c, mp.gamma_g, flip));
     DevBuf& gl = ctx->buf("grayL");
     DevBuf& gr = ctx->buf("grayR");
     ASW_TRY(gl.ensure((size_t)H * W));
@@ -300,7 +304,9 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
     ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
     BilateralLaunch a;
-    a.gL = gl.as<uint8_t>(); a.gR = gr.as<uint8_t>();
+    a.gL = flip ? gr.as<uint8_t>() : gl.as<uint8_t>();  // RIGHT: reference image = right, read mirrored in the kernel
+    a.gR = flip ? gl.as<uint8_t>() : gr.as<uint8_t>();
+    a.flip = flip;
     a.H = H; a.W = W; a.win = mp.win; a.minD = mp.minD; a.nD = nD;
     a.taps = ctx->bil.taps.as<int4>(); a.lut = ctx->bil.lut.as<float>(); a.ntaps = ctx->bil.ntaps;
     a.vol = keep_volume ? f->vol.as<float>() : nullptr;
@@ -336,8 +342,9 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
 {
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
     // GuidedF_2: RIGHT / gray branches of computeSimilarity throw in the reference (App. B-7).
-    // GuidedF RIGHT exists in the reference; it is a "next" row here.
-    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (variant2 && mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    const bool right = mp.disparity_type == ASW_DISPARITY_RIGHT;
     if (!variant2 && mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // getCostSAD_d, M.cpp:2458-2462
     if (mp.win < 1 || mp.win > 128) return ASW_ERR_BAD_ARGUMENT;
     const int H = f->rows, W = f->cols, n = mp.numD, C = variant2 ? 3 : 6;
@@ -368,7 +375,8 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     const uint8_t* dR = f->R.as<uint8_t>();
 
     GuidedLaunch a;
-    a.shift = variant2 ? 0 : 1; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
+    // guide = [L, R shifted by -d] (LEFT, M.cpp:2907-2912) or [L shifted by +d, R] (RIGHT, M.cpp:2925-2929)
+    a.shiftA = (!variant2 && right) ? 1 : 0; a.shiftB = (!variant2 && !right) ? -1 : 0; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
     ASW_TRY(launch_pack_words(ctx->stream, dL, H, W, 3, 0, pxa.as<uint32_t>()));
     if (!variant2) ASW_TRY(launch_pack_words(ctx->stream, dR, H, W, 3, 0, pxb.as<uint32_t>()));
     a.guideA = pxa.as<uint32_t>(); a.guideB = variant2 ? nullptr : pxb.as<uint32_t>();
@@ -387,8 +395,8 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
         ASW_TRY(launch_bgr2gray(ctx->stream, dR, H, W, gr.as<uint8_t>()));
         ASW_TRY(launch_cost_sad(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, n,
                                 raw.as<float>()));  // M.cpp:2884-2889
-        ASW_TRY(launch_guide_scales_lr(ctx->stream, dL, dR, H, W, mp.minD, n, mp.disparity_type, ord.as<uint32_t>() + 2 * n,
-                                       colmm.as<int>(), gsc.as<float2>()));
+        ASW_TRY(launch_guide_scales_lr(ctx->stream, right ? dR : dL, right ? dL : dR, H, W, mp.minD, n, mp.disparity_type,
+                                       ord.as<uint32_t>() + 2 * n, colmm.as<int>(), gsc.as<float2>()));
     }
     if (!variant2)
         ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));  // M.cpp:2775
@@ -410,7 +418,8 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
 {
     if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:1440-1443
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;  // at<Vec3b>
-    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;  // RIGHT: next row
+    if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    const int flip = mp.disparity_type == ASW_DISPARITY_RIGHT ? 1 : 0;  // M.cpp:1498-1520 == LEFT on the mirrored problem
     if (mp.win < 1 || mp.win > 35) return ASW_ERR_BAD_ARGUMENT;
     const int H = f->rows, W = f->cols, nD = mp.numD + 1;  // inclusive range, M.cpp:1447,1467
     const size_t plane = (size_t)H * W, cells = (size_t)mp.win * mp.win;
@@ -433,8 +442,12 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pl.as<uint32_t>(), H, W, mp.win, 3, wl.as<uint16_t>()));  // M.cpp:1464
     ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pr.as<uint32_t>(), H, W, mp.win, 3, wr.as<uint16_t>()));  // M.cpp:1465
-    ASW_TRY(launch_asw_geodesic(ctx->stream, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
-                                mp.win, mp.minD, nD, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+    if (!flip)
+        ASW_TRY(launch_asw_geodesic(ctx->stream, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
+                                    mp.win, mp.minD, nD, 0, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+    else
+        ASW_TRY(launch_asw_geodesic(ctx->stream, pr.as<uint32_t>(), pl.as<uint32_t>(), wr.as<uint16_t>(), wl.as<uint16_t>(), H, W,
+                                    mp.win, mp.minD, nD, 1, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->timing.aggregate_launches = 3;
     return ASW_OK;
@@ -776,7 +789,7 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     ASW_TRY(launch_u8_scale(ctx->stream, dg.as<uint8_t>(), plane * C, ord.as<uint32_t>() + 2, gsc.as<float2>()));  // M.cpp:2774
     ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), 1, plane, ord.as<uint32_t>(), psc.as<float2>()));     // M.cpp:2775
     GuidedLaunch a;
-    a.shift = 0; a.C = C; a.guide_per_slice = 0;
+    a.shiftA = 0; a.shiftB = 0; a.C = C; a.guide_per_slice = 0;
     a.guideA = pxa.as<uint32_t>(); a.guideB = C == 6 ? pxb.as<uint32_t>() : nullptr;
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;

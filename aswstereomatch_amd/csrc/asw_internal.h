@@ -39,8 +39,9 @@ struct Frame {
     bool valid = false;
 };
 
-struct BilateralTables {  // cached per (win, gamma_c, gamma_g)
+struct BilateralTables {  // cached per (win, gamma_c, gamma_g, mirror)
     int win = 0;
+    int mirror = -1;
     double gamma_c = 0, gamma_g = 0;
     int ntaps = 0, ncls = 0;
     DevBuf taps;  // int4 per tap
@@ -75,6 +76,7 @@ struct BilateralLaunch {
     const int4* taps;         // {sample cell offset dys*LW+dxs, weight dx, weight dy, class*256}
     const float* lut;         // [ncls][256]
     int ntaps;
+    int flip;    // 1: mirrored problem (DISPARITY_RIGHT), taps must come from the mirrored table
     float* vol;  // optional [nD][H][W]
     float* disp; // [H][W]
 };
@@ -103,7 +105,7 @@ int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, 
 struct GuidedLaunch {
     const uint32_t* guideA; // BGRX plane holding guide channels 0..2
     const uint32_t* guideB; // BGRX plane holding guide channels 3..5 (C = 6), else null
-    int shift;              // 1: channels 3..5 are read at reflect(x - d) (GuidedF), 0: at x
+    int shiftA, shiftB;     // plane A / B is read at reflect(x + shift*d): GuidedF LEFT = (0,-1), RIGHT = (+1,0); else 0
     int C;                  // 3 or 6
     int guide_per_slice;    // 1: guide (hence its statistics and scales) changes with the slice
     const float2* gscales;  // guide normalize() parameters (1 or n entries)
@@ -126,7 +128,7 @@ int launch_geodesic_weights_u16(hipStream_t s, const uint32_t* img, int H, int W
 int launch_geodesic_weights_f32(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, float* planes);
 int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, int cells, float* out);
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
-                        int H, int W, int win, int minD, int nD, float* vol, float* disp);
+                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp);
 
 // ---- weighted median (k_wmedian.hip) ----
 int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,

@@ -37,6 +37,7 @@ constexpr int DCMAX = 16;  // widest d-chunk
 
 struct BilParams {
     int H, W, h, minD, nD, ntaps;
+    int flip;  // 1: the problem is mirrored in x (DISPARITY_RIGHT = DISPARITY_LEFT on mirrored, swapped images)
 };
 
 constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -104,7 +105,7 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     for (int i = tid; i < TR * RW; i += 256) {
         int r = i / RW, c = i - r * RW;
         int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
-        sR[r * RWp + c] = gR[(size_t)yy * W + xx];
+        sR[r * RWp + c] = gR[(size_t)yy * W + (p.flip ? W - 1 - xx : xx)];
     }
     __syncthreads();
     // cost tile: C[r][c][dd] = |gL(ny,nx) - gR(ny, max(0, nx-d))|   (M.cpp:1106)
@@ -203,7 +204,7 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
 #pragma unroll
         for (int dd = 0; dd < DC; dd++) {
             double E = num[dd] / den[dd];  // M.cpp:1111
-            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + x] = (float)E;
+            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + (p.flip ? W - 1 - x : x)] = (float)E;
             if (E < bestE) {  // M.cpp:1145-1150, ascending d, strict <
                 bestE = E;
                 bestD = (float)(d0 + dd);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = tid; i < lay.TR * lay.LW; i += 256) {
         int r = i / lay.LW, c = i - r * lay.LW;
         int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(x0 - h + c, 0), W - 1);
-        sL[r * lay.LWp + c] = gL[(size_t)yy * W + xx];
+        sL[r * lay.LWp + c] = gL[(size_t)yy * W + (p.flip ? W - 1 - xx : xx)];
     }
 
     double bestE = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
@@ -241,14 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if (p.nD - c0 >= 1) { process_chunk<1, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 1; }
 
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
-    if (x < W && y < H) disp[(size_t)y * W + x] = bestD;
+    if (x < W && y < H) disp[(size_t)y * W + (p.flip ? W - 1 - x : x)] = bestD;
 }
 
 template <int HH, int G, int WPE = 2>
 int launch_t(hipStream_t s, const BilateralLaunch& a)
 {
     BilParams p;
-    p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps;
+    p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps; p.flip = a.flip;
     const Layout lay(p.h, G);
     if (lay.total > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     auto kern = k_asw_bilateral<HH, G, WPE>;

@@ -149,6 +149,7 @@ constexpr int TW = 64, TH = 4, GDC = 8, GG = 5;  // tile, disparities per thread
 
 struct GeoParams {
     int H, W, win, minD, nD;
+    int flip;  // 1: mirrored problem (DISPARITY_RIGHT): images / weight planes are read at W-1-x, window columns reversed
 };
 
 template <int DC>
@@ -176,7 +177,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     for (int i = tid; i < TR * RW; i += 256) {
         int r = i / RW, c = i - r * RW;
         int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
-        sR[r * RWmax + c] = imgR[(size_t)yy * W + xx];
+        sR[r * RWmax + c] = imgR[(size_t)yy * W + (p.flip ? W - 1 - xx : xx)];
     }
     __syncthreads();
     // colour-L1 cost tile: C[r][c][dd] = |L(ny,nx) - R(ny, max(0,nx-d))|_1   (M.cpp:1490)
@@ -197,7 +198,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     for (int dd = 0; dd < DC; dd++) { num[dd] = 0.0; den[dd] = 0.0; }
     const int x = x0 + tx, y = y0 + ty;
     const int xc = min(x, W - 1), yc = min(y, H - 1);
-    const uint16_t* myWL = wL + (size_t)yc * W + xc;
+    const uint16_t* myWL = wL + (size_t)yc * W + (p.flip ? W - 1 - xc : xc);
     const uint16_t* myC = sC + (size_t)(ty * LW + tx) * DC;
     const float* myWR = sWR + ty * (TW + GDC - 1) + tx + (DC - 1);
     const int ntaps = win * win;
@@ -212,13 +213,19 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
             int row = rem / SWR, jj = rem - row * SWR;
             int xr = min(max(x0 - d0 - (DC - 1) + jj, 0), W - 1);
             int yy = min(y0 + row, H - 1);
-            sWR[(tt * TH + row) * (TW + GDC - 1) + jj] = (float)wR[(size_t)(g0 + tt) * plane + (size_t)yy * W + xr];
+            int tcell = g0 + tt;
+            if (p.flip) { int tj = tcell / win; tcell = tj * win + (win - 1 - (tcell - tj * win)); }  // reversed window column
+            sWR[(tt * TH + row) * (TW + GDC - 1) + jj] = (float)wR[(size_t)tcell * plane + (size_t)yy * W + (p.flip ? W - 1 - xr : xr)];
         }
-        float wl_next = (float)myWL[(size_t)g0 * plane];
+        auto wl_cell = [&](int t, int tj, int ti) { return (size_t)(p.flip ? tj * win + (win - 1 - ti) : t) * plane; };
+        float wl_next = (float)myWL[wl_cell(g0, j, i)];
         __syncthreads();
         for (int tt = 0; tt < ng; tt++) {
             const float wl = wl_next;
-            if (g0 + tt + 1 < ntaps) wl_next = (float)myWL[(size_t)(g0 + tt + 1) * plane];  // next tap's weight in flight
+            if (g0 + tt + 1 < ntaps) {  // next tap's weight in flight
+                const int ni = (i + 1 == win) ? 0 : i + 1, nj = (i + 1 == win) ? j + 1 : j;
+                wl_next = (float)myWL[wl_cell(g0 + tt + 1, nj, ni)];
+            }
             const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
             uint32_t cw[(DC + 1) / 2];
             if constexpr (DC == 8) {
@@ -248,7 +255,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
 #pragma unroll
         for (int dd = 0; dd < DC; dd++) {
             double E = num[dd] / den[dd];  // 0/0 -> NaN for windows flat in both images (App. B-9)
-            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + x] = (float)E;
+            if (vol) vol[((size_t)(c0 + dd) * H + y) * W + (p.flip ? W - 1 - x : x)] = (float)E;
             if (E < bestE) { bestE = E; bestD = (float)(d0 + dd); }
         }
     }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = tid; i < TR * LW; i += 256) {
         int r = i / LW, c = i - r * LW;
         int yy = min(max(y0 - h + r, 0), p.H - 1), xx = min(max(x0 - h + c, 0), p.W - 1);
-        sL[i] = imgL[(size_t)yy * p.W + xx];
+        sL[i] = imgL[(size_t)yy * p.W + (p.flip ? p.W - 1 - xx : xx)];
     }
     double bestE = 1.7976931348623157e308;
     float bestD = 0.0f;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (p.nD - c0 >= 2) { geo_chunk<2>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
     if (p.nD - c0 >= 1) { geo_chunk<1>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
-    if (x < p.W && y < p.H) disp[(size_t)y * p.W + x] = bestD;
+    if (x < p.W && y < p.H) disp[(size_t)y * p.W + (p.flip ? p.W - 1 - x : x)] = bestD;
 }
 
 template <int WIN, typename OutT>
@@ -332,9 +339,9 @@ int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, i
 }
 
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
-                        int H, int W, int win, int minD, int nD, float* vol, float* disp)
+                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp)
 {
-    GeoParams p{H, W, win, minD, nD};
+    GeoParams p{H, W, win, minD, nD, flip};
     const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
     size_t lds = (size_t)TR * LW * GDC * 2 + (size_t)GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
     if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;

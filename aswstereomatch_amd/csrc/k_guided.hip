@@ -151,19 +151,19 @@ __global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W,
 
 // ---- guide access: normalised guide channels I_c(y,x) for slice k --------------------------------
 // The guide lives in packed BGRX planes (one dword per pixel): channels 0-2 from A at x; channels 3-5 from B
-// at x (shift = 0: 6-channel guide of the public getGuidedFilter) or at reflect(x - d) (shift = 1: the
-// disparity-shifted right image of computeAdaptiveWeight_GuidedF, M.cpp:2907-2912).
+// at x, or either plane at reflect(x + shift*d): the disparity-shifted view of computeAdaptiveWeight_GuidedF
+// (LEFT: right image at x-d, M.cpp:2907-2912; RIGHT: left image at x+d, M.cpp:2925-2929).
 struct GuideAcc {
     const uint32_t* A;
     const uint32_t* B;
     const float2* scales;  // normalize() scale/shift per slice (index k * scale_stride)
     int scale_stride;
-    int W, shift, minD;
+    int W, shiftA, shiftB, minD;
     template <int NW>
     __device__ __forceinline__ void fetch(int y, int x, int k, uint32_t (&u)[NW]) const
     {
-        u[0] = A[(size_t)y * W + x];
-        if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shift ? reflect_idx(x - (minD + k), W) : x)];
+        u[0] = A[(size_t)y * W + (shiftA ? reflect_idx(x + shiftA * (minD + k), W) : x)];
+        if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shiftB ? reflect_idx(x + shiftB * (minD + k), W) : x)];
     }
     template <int NW>
     __device__ __forceinline__ void eval(const uint32_t (&u)[NW], int k, float (&I)[3 * NW]) const
@@ -432,7 +432,7 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
 {
     GuideAcc g;
     g.A = a.guideA; g.B = a.guideB; g.scales = a.gscales; g.scale_stride = a.guide_per_slice ? 1 : 0;
-    g.W = a.W; g.shift = a.shift; g.minD = a.minD;
+    g.W = a.W; g.shiftA = a.shiftA; g.shiftB = a.shiftB; g.minD = a.minD;
     const int nstat = a.guide_per_slice ? a.n : 1;
     const float epsf = (float)a.eps;
     int rc;

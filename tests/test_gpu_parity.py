@@ -264,3 +264,46 @@ def test_all_methods_recover_shift_k6(ctx):
     for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_MEDIAN):
         d = ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
         assert (d[8:-8, 16:-8] == d0).all(), alg
+
+
+# ---------------------------------------------------------------- DISPARITY_RIGHT
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (37, 130, 7, 0, 20, 4), (20, 70, 15, 2, 33, 5), (12, 64, 3, 0, 80, 6)])
+def test_classic_right_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_classic(L, R, 30, 20, 1, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and np.array_equal(v_got, v_want) and np.array_equal(d_got, d_want)
+    assert np.array_equal(ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT, win, minD, numD), d_want)
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (37, 130, 7, 0, 20, 4), (20, 70, 15, 2, 33, 5)])
+def test_geodesic_right_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_geodesic(L, R, 1, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_geodesic(L, R, RIGHT, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and np.array_equal(v_got, v_want, equal_nan=True) and np.array_equal(d_got, d_want)
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (40, 270, 15, 0, 12, 4), (30, 100, 7, 2, 9, 5)])
+def test_guided_right_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_guided(L, R, 1, 1e-6, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_GuidedF(L, R, RIGHT, 1e-6, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and np.abs(v_got - v_want).max() < 1e-4 and np.array_equal(d_got, d_want)
+
+
+def test_right_unsupported_where_reference_throws(ctx):
+    L, R, _ = make_pair(16, 32, 4, seed=1)
+    for alg in (A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_MEDIAN):   # App. B-7 / B-13
+        with pytest.raises(asw.AswError) as e:
+            ctx.stereoMatching(L, R, RIGHT, alg, 5, 0, 4)
+        assert e.value.status == asw.ERR_UNSUPPORTED_LAYOUT
+
+
+def test_right_recovers_shift(ctx):
+    # L(x) = R(x - d0)  <=>  R(x) = L(x + d0): the right-referenced disparity is d0 as well
+    d0 = 5
+    L, R = shifted_pair(40, 64, d0)
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GEODESIC):
+        d = ctx.stereoMatching(L, R, RIGHT, alg, 7, 0, 8)
+        assert (d[8:-8, 8:-16] == d0).all(), alg
