@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step (C5: 64 frames / 8 GPUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,17 +113,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device_index = local_rank % max(1, ndev)  # one process per GPU; wraps only when rehearsing N ranks on fewer GPUs
+    torch.cuda.set_device(device_index)
     import aswstereomatch_amd as asw
     from aswstereomatch_amd.dist import Group
     from aswstereomatch_amd.synth import make_pair
 
-    group = Group(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+    group = Group(backend=args.backend, device=torch.device("cuda", device_index) if args.backend == "nccl" else None)
 
     alg, ncand_fn, label = WORKLOADS[args.workload]
     W, H, D = args.width, args.height, args.disp
     ncand = ncand_fn(D)
-    ctx = asw.Context(local_rank)
+    ctx = asw.Context(device_index)
 
     # synthetic frames of the named shape, resident in HBM before the timed region
     frames = []
