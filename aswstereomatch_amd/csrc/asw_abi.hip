@@ -268,8 +268,10 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double
     }
     ASW_TRY(t.taps.ensure(taps.size() * sizeof(int4)));
     ASW_TRY(t.lut.ensure(lut.size() * sizeof(float)));
-    ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!taps.empty()) {  // win = 1 has no taps at all (every E is 0/0)
+        ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
     t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.mirror = mirror; t.ntaps = nt; t.ncls = (int)r2s.size();
     return ASW_OK;
@@ -284,7 +286,8 @@ struct MatchParams {
 
 static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
 {
-    if (mp.win % 2 == 0 || mp.win < 3) return ASW_ERR_EVEN_WINDOW;
+    if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // build decision: the reference has no guard
+    if (mp.win < 1) return ASW_ERR_BAD_ARGUMENT;
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;  // cvtColor(BGR2GRAY) asserts scn==3/4
     if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
     const int flip = mp.disparity_type == ASW_DISPARITY_RIGHT ? 1 : 0;

@@ -392,6 +392,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     const int XO = SW - (k - 1);
     const int nxw = (W + XO - 1) / XO;
     int band = 64;
+    if (const char* e = getenv("ASW_BAND")) band = atoi(e);
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
     size_t lds = (size_t)4 * NP * (SW + 2) * sizeof(double);
     auto kern = k_box_walk<NP, CPL, PF, Src, Dst>;

@@ -1,0 +1,117 @@
+"""Edge cases the reference's loops admit: tiny and ragged images, windows larger than the image, disparity
+ranges larger than the width, minDisparity > 0, 1-pixel windows, constant images."""
+import numpy as np
+import pytest
+
+import aswstereomatch_amd as asw
+from aswstereomatch_amd.synth import make_pair
+
+pytestmark = pytest.mark.gpu
+A = asw.StereoMatchingAlgorithms
+LEFT, RIGHT = asw.DISPARITY_LEFT, asw.DISPARITY_RIGHT
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = asw.Context(0)
+    yield c
+    c.close()
+
+
+def _pair(H, W, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 256, (H, W, 3)).astype(np.uint8), rng.integers(0, 256, (H, W, 3)).astype(np.uint8))
+
+
+SHAPES = [(1, 1), (1, 7), (5, 1), (3, 5), (2, 65), (7, 63), (4, 64), (5, 129), (9, 200)]
+
+
+@pytest.mark.parametrize("H,W", SHAPES)
+def test_classic_small_shapes(ctx, oracle, H, W):
+    L, R = _pair(H, W, H * 131 + W)
+    for win, minD, numD, dt in [(3, 0, 4, 0), (7, 1, 9, 0), (15, 0, 3, 1), (5, 2, 70, 0)]:
+        rc, dw, vw = oracle.asw_classic(L, R, 30, 20, dt, win, minD, numD, want_vol=True)
+        d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, win, minD, numD, return_cost_volume=True)
+        assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw), (win, minD, numD, dt)
+
+
+def test_classic_window_one(ctx, oracle):
+    # win = 1: zero taps -> E = 0/0 = NaN for every d -> never selected -> 0 (reference: uninitialised)
+    L, R = _pair(6, 10, 1)
+    rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 1, 0, 3, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, 1, 0, 3, return_cost_volume=True)
+    assert np.isnan(vw).all() and np.isnan(v).all() and (d == 0).all() and np.array_equal(d, dw)
+
+
+@pytest.mark.parametrize("H,W", SHAPES)
+def test_geodesic_small_shapes(ctx, oracle, H, W):
+    L, R = _pair(H, W, H * 17 + W)
+    for win, minD, numD, dt in [(3, 0, 4, 0), (7, 1, 9, 1), (15, 0, 3, 0), (1, 0, 5, 0)]:
+        rc, dw, vw = oracle.asw_geodesic(L, R, dt, win, minD, numD, want_vol=True)
+        d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, win, minD, numD, return_cost_volume=True)
+        assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw), (win, minD, numD, dt)
+    rc, ww = oracle.geodesic_dist(L, 5, 3)
+    assert np.array_equal(ctx.getGeodesicDist(L, 5, 3), ww)
+
+
+@pytest.mark.parametrize("H,W", SHAPES)
+def test_costs_small_shapes(ctx, oracle, H, W):
+    L, R = _pair(H, W, H * 7 + W)
+    for dt in (0, 1):
+        assert np.array_equal(np.stack(ctx.computeAD(L, R, dt, 1, 6)), oracle.compute_ad(L, R, dt, 1, 6)[1])
+        assert np.array_equal(np.stack(ctx.getCostSAD(L, R, dt, 5, 0, 4)), oracle.cost_sad(L, R, dt, 5, 0, 4)[1])
+    assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 2, 5)), oracle.compute_similarity(L, R, 0.4, 10, 50, 0, 2, 5)[1])
+    assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.3, 7, 40, LEFT, 0, 3, winSize=5)),
+                          oracle.compute_similarity(L, R, 0.3, 7, 40, 0, 0, 3, win=5)[1])
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (2, 65), (7, 63), (5, 129), (20, 130)])
+def test_guided_and_median_small_shapes(ctx, oracle, H, W):
+    L, R = _pair(H, W, H * 3 + W)
+    for win in (3, 5, 15):
+        rc, dw, vw = oracle.asw_guided2(L, R, 0, 1e-6, win, 1, 5, want_vol=True)
+        d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, win, 1, 5, return_cost_volume=True)
+        assert rc == 0 and np.abs(v - vw).max() < 1e-4 and np.array_equal(d, dw), ("g2", win)
+        for dt in (0, 1):
+            rc, dw, vw = oracle.asw_guided(L, R, dt, 1e-6, win, 0, 4, want_vol=True)
+            d, v = ctx.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, win, 0, 4, return_cost_volume=True)
+            assert rc == 0 and np.abs(v - vw).max() < 1e-4 and np.array_equal(d, dw), ("g", win, dt)
+        rc, dw, vw = oracle.asw_wmedian(L, R, 0, win, 10, 10, 1, 5, want_vol=True)
+        d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, win, 10, 10, 1, 5, return_cost_volume=True)
+        assert rc == 0 and np.array_equal(v, vw) and np.array_equal(d, dw), ("wm", win)
+
+
+def test_even_guided2_window_is_accepted_like_the_reference(ctx, oracle):
+    # GuidedF_2 has no parity check on winSize: boxFilter(Size(6,6)) uses anchor 3 (M.cpp:2976-3006)
+    L, R, _ = make_pair(20, 40, 6, seed=3, block=8)
+    rc, dw, vw = oracle.asw_guided2(L, R, 0, 1e-6, 6, 0, 6, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, 6, 0, 6, return_cost_volume=True)
+    assert rc == 0 and np.abs(v - vw).max() < 1e-4 and np.array_equal(d, dw)
+
+
+def test_constant_images(ctx, oracle):
+    L = np.full((10, 20, 3), 9, np.uint8)
+    R = L.copy()
+    for alg, fn in [(A.ADAPTIVE_WEIGHT, lambda: oracle.stereo_matching(L, R, 0, 2, 5, 0, 4)),
+                    (A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, lambda: oracle.stereo_matching(L, R, 0, 8, 5, 0, 4)),
+                    (A.ADAPTIVE_WEIGHT_GUIDED_FILTER, lambda: oracle.stereo_matching(L, R, 0, 7, 5, 0, 4)),
+                    (A.ADAPTIVE_WEIGHT_MEDIAN, lambda: oracle.stereo_matching(L, R, 0, 10, 5, 0, 4))]:
+        rc, want = fn()
+        assert rc == 0 and np.array_equal(ctx.stereoMatching(L, R, LEFT, alg, 5, 0, 4), want), alg
+
+
+def test_bad_arguments(ctx):
+    L, R = _pair(8, 8, 1)
+    for bad in [dict(numDisparity=0), dict(minDisparity=-1)]:
+        with pytest.raises(asw.AswError) as e:
+            ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 5, bad.get("minDisparity", 0), bad.get("numDisparity", 4))
+        assert e.value.status == asw.ERR_BAD_ARGUMENT
+    with pytest.raises(TypeError):
+        ctx.stereoMatching(L.astype(np.float32), R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4)
+    with pytest.raises(asw.AswError):   # weighted median above the 256-slot network
+        ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, 17, 0, 4)
+    # non-contiguous (strided) inputs are honoured through asw_image.step
+    big = np.zeros((8, 16, 3), np.uint8)
+    big[:, ::2] = L
+    d1 = ctx.stereoMatching(big[:, ::2], R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4)
+    assert np.array_equal(d1, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4))
