@@ -7,10 +7,10 @@
 // cost of the element BEFORE the crossing one (or the first one), M.cpp:3276-3304 (App. B-13).
 //
 // GPU mapping: one wavefront per pixel, looping over d.  The 225 pairs of a 15x15 window sit 4 per lane
-// (256 slots, padded with +inf keys / zero weights).  A 64-bit key (order-preserving cost bits << 32 |
-// window index) makes a plain bitonic network a STABLE sort: 15 intra-lane and 21 cross-lane
-// compare-exchange steps (DPP/bpermute shuffles), no payload is moved -- the weight of a sorted
-// element is fetched from LDS by its window index afterwards.  Prefix sums are a per-lane chain plus a
+// (256 slots, padded with max keys / zero weights).  A key made of (order-preserving cost bits, window
+// index) makes a plain bitonic network a STABLE sort: 15 intra-lane and 21 cross-lane compare-exchange
+// steps (DPP / ds_swizzle / bpermute), no payload is moved -- the weight of a sorted element is fetched
+// from LDS by its window index afterwards.  Prefix sums are a per-lane chain plus a
 // wavefront scan in f64.  Window weights are read in the reference's own per-pixel layout
 // [y][x][cell] (900 contiguous bytes per pixel -> coalesced): the left one premultiplied by the space
 // kernel once per frame, the right one for the REFLECT-padded right image (M.cpp:3246, 3263).
@@ -61,49 +61,75 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(u);
 }
 
-typedef unsigned long long u64;
+// ---- 32-bit sort keys ---------------------------------------------------------------------------
+// The TAD C+G cost with the method's literals (0.4, 10, 50; M.cpp:3250) is 0.6*cc + 0.4*cg with cc in [0,255]
+// and cg in [12700, 12700+8160]: every cost lies in [4096, 16384), i.e. its f32 bit pattern minus that of
+// 4096.0f fits in 24 bits and is order preserving.  key = (that << 8) | window index is a 32-bit key whose
+// unsigned order is exactly the multimap's (cost, insertion order) -> v_min_u32 / v_max_u32 do the
+// compare-exchange, no 64-bit compares.
+constexpr uint32_t COST_BASE_BITS = 0x45800000u;  // 4096.0f
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
 {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = (uint32_t)__shfl_xor((int)lo, mask);
-    hi = (uint32_t)__shfl_xor((int)hi, mask);
-    return ((u64)hi << 32) | lo;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// 256-key ascending bitonic sort across one wavefront, element e = lane*4 + r
-__device__ __forceinline__ void bitonic256(u64 (&key)[4], int lane)
+// value of lane (lane ^ LM)
+template <int LM>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
 {
+    if constexpr (LM == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if constexpr (LM == 2) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (LM == 8) return dpp_mov<0x128>(v);  // row_ror:8 == xor 8 inside a 16-lane row
+    else if constexpr (LM == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
+    else if constexpr (LM == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1f);
+    else return (uint32_t)__shfl_xor((int)v, LM);
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step(uint32_t (&key)[4], int lane)
+{
+    if constexpr (J >= 4) {
+        constexpr int LM = J >> 2;
+        const bool up = ((lane * 4) & K) == 0;  // K >= 8: direction depends on the lane only
+        const bool lower = (lane & LM) == 0;
+        const bool take_min = (up == lower);    // loop invariant: lives in an SGPR pair
 #pragma unroll
-    for (int k = 2; k <= 256; k <<= 1) {
+        for (int r = 0; r < 4; r++) {
+            const uint32_t o = lane_xor<LM>(key[r]);
+            const uint32_t mn = min(key[r], o), mx = max(key[r], o);
+            key[r] = take_min ? mn : mx;
+        }
+    } else {
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 4) {
-                const int lm = j >> 2;
-                const bool up = ((lane * 4) & k) == 0;   // k >= 8 here: direction depends on the lane only
-                const bool lower = (lane & lm) == 0;
-                const bool take_min = (up == lower);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    u64 o = shfl_xor_u64(key[r], lm);
-                    u64 mn = key[r] < o ? key[r] : o, mx = key[r] < o ? o : key[r];
-                    key[r] = take_min ? mn : mx;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int q = r ^ j;
-                    if (q > r) {
-                        const bool up = ((lane * 4 + r) & k) == 0;
-                        u64 a = key[r], b = key[q];
-                        u64 mn = a < b ? a : b, mx = a < b ? b : a;
-                        key[r] = up ? mn : mx;
-                        key[q] = up ? mx : mn;
-                    }
-                }
+        for (int r = 0; r < 4; r++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int q = r ^ J;
+            if (q > r) {
+                const bool up = ((lane * 4 + r) & K) == 0;
+                const uint32_t a = key[r], b = key[q];
+                const uint32_t mn = min(a, b), mx = max(a, b);
+                key[r] = up ? mn : mx;
+                key[q] = up ? mx : mn;
             }
         }
     }
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&key)[4], int lane)
+{
+    bitonic_step<K, J>(key, lane);
+    if constexpr (J > 1) bitonic_merge<K, J / 2>(key, lane);
+}
+
+template <int K>
+__device__ __forceinline__ void bitonic_sort(uint32_t (&key)[4], int lane)
+{
+    if constexpr (K > 2) bitonic_sort<K / 2>(key, lane);
+    bitonic_merge<K, K / 2>(key, lane);
 }
 
 constexpr int WM_WAVES = 4;
@@ -140,17 +166,17 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
         const float* wr = wRb + ((size_t)y * Wb + cb) * n;
         const float* cp = cost + (size_t)d * plane;
         float w[4];
-        u64 key[4];
+        uint32_t key[4];
         double s_loc = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int e = lane * 4 + r;
             if (valid[r]) {
                 w[r] = wl[r] * wr[e];  // (wL .mul wd) .mul wR, f32
-                key[r] = ((u64)f2ord(cp[off[r]]) << 32) | (uint32_t)e;
+                key[r] = ((__float_as_uint(cp[off[r]]) - COST_BASE_BITS) << 8) | (uint32_t)e;
             } else {
                 w[r] = 0.0f;
-                key[r] = ~0ull;
+                key[r] = 0xffffffffu;
             }
             s_loc += (double)w[r];
             sW[wv][e] = w[r];
@@ -161,17 +187,17 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         const double half = tot / 2;
 
-        bitonic256(key, lane);
+        bitonic_sort<256>(key, lane);
 
         // weights in sorted order, inclusive prefix sums in f64
         double pre[4];
         double run = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint32_t idx = (uint32_t)key[r] & 0xffu;
+            const uint32_t idx = key[r] & 0xffu;
             run += (double)sW[wv][idx];   // same-wave LDS: written above by this wave, in program order
             pre[r] = run;
-            sK[wv][lane * 4 + r] = (uint32_t)(key[r] >> 32);
+            sK[wv][lane * 4 + r] = key[r];
         }
         double incl = run;  // wave inclusive scan of the lane totals
 #pragma unroll
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
             const int fr = __shfl(first, fl);
             const int kpos = fl * 4 + fr;
             const int take = kpos == 0 ? 0 : kpos - 1;  // predecessor of the crossing element (M.cpp:3293-3301)
-            res = ord2f(sK[wv][take]);
+            res = __uint_as_float((sK[wv][take] >> 8) + COST_BASE_BITS);
         }
         if (lane == 0) out[(size_t)d * plane + pix] = res;
     }
