@@ -79,7 +79,7 @@ def cpu_baseline(args, L, R, gpu_disp, alg):
 
     fn = {4: lambda a, b: O.asw_geodesic(a, b, 0, win, 0, D), 7: lambda a, b: O.asw_guided(a, b, 0, 1e-6, win, 0, D),
           8: lambda a, b: O.asw_guided2(a, b, 0, 1e-6, win, 0, D), 10: lambda a, b: O.asw_wmedian(a, b, 0, win, 10, 10, 0, D)}[alg]
-    sw, sh = {4: (621, 188), 7: (1280, 720), 8: (1920, 1080), 10: (311, 94)}[alg]  # sized for ~10-20 s on 16 cores
+    sw, sh = {4: (1242, 375), 7: (1280, 720), 8: (1920, 1080), 10: (621, 188)}[alg]  # sized for ~3-10 s on 16 cores
     sw, sh = min(sw, W), min(sh, H)
     Ls, Rs, _ = make_pair(sh, sw, min(D, sw // 2), seed=4321)
     t = time.time()
