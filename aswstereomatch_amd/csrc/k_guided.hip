@@ -37,23 +37,30 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 //   * vertical running sums in f64 registers (add the entering row, subtract the leaving one -- ColumnSum's
 //     sliding form; the leaving row is re-fetched from cache rather than kept: an LDS ring cost 61 KB per
 //     workgroup and 2x the run time);
-//   * the operands of step s+1 (Src::fetch / Dst::fetch: loads only) are issued before the arithmetic of
-//     step s, so their latency hides behind it;
 //   * horizontal sums through a wave-private LDS strip: LDS operations of one wavefront execute in order, so
 //     no workgroup barrier is needed; a lane's second column reuses the first one's sum (- b[0] + b[k]).
-template <int NP, int CPL, bool PF, class Src, class Dst>
-__global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw)
+//   * ND slices per wavefront: operands that do not depend on the slice (guide pixel, guide statistics) are
+//     fetched once -- the ND fetches are issued back to back with identical addresses and merge (CSE).
+template <int NP, int CPL, int ND, int WPE, class Src, class Dst>
+__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices)
 {
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kz = blockIdx.z;
-    double* hs = reinterpret_cast<double*>(smem) + (size_t)wv * NP * (SW + 2);  // [NP][SW+2] per wavefront
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* hs = reinterpret_cast<double*>(smem) + (size_t)wv * ND * NP * (SW + 2);  // [ND][NP][SW+2] per wavefront
     const int hl = k / 2;  // OpenCV anchor = k/2 (also for even k)
     const int XO = SW - (k - 1);
     const int xw = blockIdx.x * 4 + wv;  // wavefront's strip index
     if (xw >= nxw) return;               // whole wavefront exits
     const int xo0 = xw * XO;
     const int c0 = CPL * lane;           // first strip column of this lane
+    int kz[ND];
+    bool kvalid[ND];
+#pragma unroll
+    for (int n = 0; n < ND; n++) {
+        kvalid[n] = (int)blockIdx.z * ND + n < nslices;
+        kz[n] = min((int)blockIdx.z * ND + n, nslices - 1);
+    }
     int xin[CPL];
     bool out_col[CPL];
 #pragma unroll
@@ -64,85 +71,76 @@ __global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W,
     const bool any_out = out_col[0];  // columns are adjacent: column 1 is an output only if column 0 is
     const int y0 = blockIdx.y * band, y1 = min(H, y0 + band);
     const double scale = 1.0 / ((double)k * (double)k);
-    double vs[CPL][NP];
+    double vs[CPL][ND][NP];
 #pragma unroll
     for (int c = 0; c < CPL; c++)
 #pragma unroll
-        for (int p = 0; p < NP; p++) vs[c][p] = 0.0;
+        for (int n = 0; n < ND; n++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) vs[c][n][p] = 0.0;
 
     const int steps = (y1 - y0) + k - 1;
-    typename Src::Raw rn[CPL], ro[CPL];
-    typename Dst::Raw rd[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        rn[c] = src.fetch(reflect101_idx(y0 - hl, H), xin[c], kz);
-        ro[c] = rn[c];
-        rd[c] = dst.fetch(y0, min(xo0 + c0 + c, W - 1), kz);
-    }
     for (int s = 0; s < steps; s++) {
-        if (!PF && s > 0) {  // no prefetch: fetch this step's operands now
-            const int yn = reflect101_idx(y0 - hl + s, H);
-            const int yo = reflect101_idx(y0 - hl + s - k, H);
-            const int yd = min(max(y0 + s - (k - 1), y0), y1 - 1);
+        const int yn = reflect101_idx(y0 - hl + s, H);
+        const int yo = reflect101_idx(y0 - hl + s - k, H);
+        const int yd = min(max(y0 + s - (k - 1), y0), y1 - 1);
+        // ---- all loads of this step, back to back (no store in between: equal addresses merge) ----
+        typename Src::Raw rn[CPL][ND], ro[CPL][ND];
+        typename Dst::Raw rd[CPL][ND];
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                rn[c] = src.fetch(yn, xin[c], kz);
-                if (s >= k) ro[c] = src.fetch(yo, xin[c], kz);
-                if (s >= k - 1) rd[c] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz);
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int n = 0; n < ND; n++) {
+                rn[c][n] = src.fetch(yn, xin[c], kz[n]);
+                if (s >= k) ro[c][n] = src.fetch(yo, xin[c], kz[n]);
+                if (s >= k - 1) rd[c][n] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz[n]);
             }
-        }
-        // ---- consume the operands fetched one step ago ----
+        // ---- vertical running sums (ColumnSum: SUM -= leaving row, SUM += entering row) ----
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            if (s >= k) {  // the row leaving the window (ColumnSum: SUM -= Sm)
-                float o[NP];
-                src.eval(ro[c], kz, o);
+        for (int c = 0; c < CPL; c++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) vs[c][p] = vs[c][p] - (double)o[p];
+            for (int n = 0; n < ND; n++) {
+                if (s >= k) {
+                    float o[NP];
+                    src.eval(ro[c][n], kz[n], o);
+#pragma unroll
+                    for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] - (double)o[p];
+                }
+                float v[NP];
+                src.eval(rn[c][n], kz[n], v);
+#pragma unroll
+                for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] + (double)v[p];
             }
-            float v[NP];
-            src.eval(rn[c], kz, v);
-#pragma unroll
-            for (int p = 0; p < NP; p++) vs[c][p] = vs[c][p] + (double)v[p];
-        }
-        typename Dst::Raw rdc[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++) rdc[c] = rd[c];
-        // ---- issue the loads of step s+1 (PF) ----
-        if (PF && s + 1 < steps) {
-            const int yn = reflect101_idx(y0 - hl + s + 1, H);
-            const int yo = reflect101_idx(y0 - hl + s + 1 - k, H);
-            const int yd = min(max(y0 + s + 1 - (k - 1), y0), y1 - 1);
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                rn[c] = src.fetch(yn, xin[c], kz);
-                if (s + 1 >= k) ro[c] = src.fetch(yo, xin[c], kz);
-                if (s + 1 >= k - 1) rd[c] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz);
-            }
-        }
         if (s >= k - 1) {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) hs[p * (SW + 2) + c0 + c] = vs[c][p];
+                for (int n = 0; n < ND; n++)
+#pragma unroll
+                    for (int p = 0; p < NP; p++) hs[(n * NP + p) * (SW + 2) + c0 + c] = vs[c][n][p];
             // same-wavefront LDS traffic is ordered: the reads below see the writes above
             if (any_out) {
-                float m[CPL][NP];
-#pragma unroll
-                for (int p = 0; p < NP; p++) {
-                    const double* b = hs + p * (SW + 2) + c0;
-                    double sum = 0.0;
-                    for (int i = 0; i < k; i++) sum = sum + b[i];
-                    m[0][p] = (float)(sum * scale);
-                    if constexpr (CPL > 1) {
-                        double sum1 = (sum - b[0]) + b[k];  // window of the adjacent column
-                        m[CPL - 1][p] = (float)(sum1 * scale);
-                    }
-                }
                 const int y = y0 + s - (k - 1);
-                dst.emit(y, xo0 + c0, kz, rdc[0], m[0]);
-                if constexpr (CPL > 1) {
-                    if (out_col[CPL - 1]) dst.emit(y, xo0 + c0 + 1, kz, rdc[CPL - 1], m[CPL - 1]);
+#pragma unroll
+                for (int n = 0; n < ND; n++) {
+                    float m[CPL][NP];
+#pragma unroll
+                    for (int p = 0; p < NP; p++) {
+                        const double* b = hs + (n * NP + p) * (SW + 2) + c0;
+                        double sum = 0.0;
+                        for (int i = 0; i < k; i++) sum = sum + b[i];
+                        m[0][p] = (float)(sum * scale);
+                        if constexpr (CPL > 1) {
+                            double sum1 = (sum - b[0]) + b[k];  // window of the adjacent column
+                            m[CPL - 1][p] = (float)(sum1 * scale);
+                        }
+                    }
+                    if (kvalid[n]) {
+                        dst.emit(y, xo0 + c0, kz[n], rd[0][n], m[0]);
+                        if constexpr (CPL > 1) {
+                            if (out_col[CPL - 1]) dst.emit(y, xo0 + c0 + 1, kz[n], rd[CPL - 1][n], m[CPL - 1]);
+                        }
+                    }
                 }
             }
         }
@@ -153,7 +151,8 @@ __global__ __launch_bounds__(BW) void k_box_walk(Src src, Dst dst, int H, int W,
 // The guide lives in packed BGRX planes (one dword per pixel): channels 0-2 from A at x; channels 3-5 from B
 // at x, or either plane at reflect(x + shift*d): the disparity-shifted view of computeAdaptiveWeight_GuidedF
 // (LEFT: right image at x-d, M.cpp:2907-2912; RIGHT: left image at x+d, M.cpp:2925-2929).
-struct GuideAcc {
+template <bool SHIFT>
+struct GuideAccT {
     const uint32_t* A;
     const uint32_t* B;
     const float2* scales;  // normalize() scale/shift per slice (index k * scale_stride)
@@ -162,13 +161,18 @@ struct GuideAcc {
     template <int NW>
     __device__ __forceinline__ void fetch(int y, int x, int k, uint32_t (&u)[NW]) const
     {
-        u[0] = A[(size_t)y * W + (shiftA ? reflect_idx(x + shiftA * (minD + k), W) : x)];
-        if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shiftB ? reflect_idx(x + shiftB * (minD + k), W) : x)];
+        if constexpr (SHIFT) {
+            u[0] = A[(size_t)y * W + (shiftA ? reflect_idx(x + shiftA * (minD + k), W) : x)];
+            if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shiftB ? reflect_idx(x + shiftB * (minD + k), W) : x)];
+        } else {  // slice-independent: the same address for every k, so fetches of several slices merge
+            u[0] = A[(size_t)y * W + x];
+            if constexpr (NW > 1) u[1] = B[(size_t)y * W + x];
+        }
     }
     template <int NW>
     __device__ __forceinline__ void eval(const uint32_t (&u)[NW], int k, float (&I)[3 * NW]) const
     {
-        const float2 sc = scales[k * scale_stride];
+        const float2 sc = scales[SHIFT ? k * scale_stride : 0];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             // convertTo 8u->32f with float scale/shift (App. A-10): v_cvt_f32_ubyteN, mul, add
@@ -186,9 +190,9 @@ struct NoRaw {};
 template <int C> struct StatStride { static constexpr int value = (C == 3) ? 8 : 12; };
 
 // box(I_c), box(I_c*I_c) -> meanI_c, den_c = (corrI_c - meanI_c^2) + eps      (M.cpp:2778, 2796-2799, 2846)
-template <int C, int W0>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
+template <int C, int W0, bool SHIFT>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
 struct StatsSrc {
-    GuideAcc g;
+    GuideAccT<SHIFT> g;
     struct Raw { uint32_t u[C / 3]; };
     __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
@@ -228,9 +232,9 @@ struct StatsDst {
 template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
 
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
-template <int C>
+template <int C, bool SHIFT>
 struct ABSrc {
-    GuideAcc g;
+    GuideAccT<SHIFT> g;
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
     int H, W;
@@ -253,17 +257,17 @@ struct ABSrc {
         for (int c = 0; c < C; c++) v[1 + c] = I[c] * p;
     }
 };
-template <int C>
+template <int C, bool PER_SLICE>  // PER_SLICE: the guide statistics depend on the slice (GuidedF)
 struct ABDst {
     const float* stats;
     float* ab;
-    int H, W, stat_stride;  // stat_stride: 1 when the guide statistics depend on the slice, else 0
+    int H, W;
     static constexpr int SS = StatStride<C>::value, AS = ABStride<C>::value;
     struct Raw { float4 s[SS / 4]; };
     __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
         Raw r;
-        const float4* p = reinterpret_cast<const float4*>(stats + (((size_t)(k * stat_stride) * H + y) * W + x) * SS);
+        const float4* p = reinterpret_cast<const float4*>(stats + (((size_t)(PER_SLICE ? k : 0) * H + y) * W + x) * SS);
 #pragma unroll
         for (int i = 0; i < SS / 4; i++) r.s[i] = p[i];
         return r;
@@ -319,9 +323,9 @@ struct QSrc {
         for (int c = 0; c < C + 1; c++) v[c] = t[c];
     }
 };
-template <int C>
+template <int C, bool SHIFT>
 struct QDst {
-    GuideAcc g;
+    GuideAccT<SHIFT> g;
     float* q;  // [n][H][W]
     int H, W;
     struct Raw { uint32_t u[C / 3]; };
@@ -384,32 +388,34 @@ struct PlaneSrc {
     __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = r.v; }
 };
 
-template <int NP, int CPL, bool PF, class Src, class Dst>
+template <int NP, int CPL, int ND, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
 {
     constexpr int SW = 64 * CPL;
     if (k < 1 || k > SW / 2) return ASW_ERR_BAD_ARGUMENT;  // k-1 halo columns must leave outputs in the strip
     const int XO = SW - (k - 1);
     const int nxw = (W + XO - 1) / XO;
-    int band = 64;
-    if (const char* e = getenv("ASW_BAND")) band = atoi(e);
+    int band = 64;  // 48..180 rows measured within +-8 %
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
-    size_t lds = (size_t)4 * NP * (SW + 2) * sizeof(double);
-    auto kern = k_box_walk<NP, CPL, PF, Src, Dst>;
-    dim3 grid((nxw + 3) / 4, (H + band - 1) / band, n);
-    hipLaunchKernelGGL(kern, grid, dim3(BW), lds, s, src, dst, H, W, k, band, nxw);
+    size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
+    // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
+    auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
+    dim3 grid((nxw + 3) / 4, (H + band - 1) / band, (n + ND - 1) / ND);
+    hipLaunchKernelGGL(kern, grid, dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
 
-template <int NP, class Src, class Dst>
+template <int NP, int ND = 1, class Src, class Dst>
 int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
 {
-    // Measured on MI355X (1080p D=128): <CPL,PF> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
+    // Measured on MI355X (1080p D=128): <CPL,prefetch> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
     // pair of launches; 24.3 / 24.9 / 24.3 / 24.1 ms for NP=7.  The kernels are bound by the memory system
     // (L2/MALL re-reads of statistics and a/b planes), not by issue: prefetching buys nothing, two adjacent
-    // columns per lane save the shared horizontal sum.
-    return launch_walk_t<NP, 2, false>(s, src, dst, H, W, k, n);
+    // columns per lane save the shared horizontal sum, ND slices per wavefront share the slice-independent loads.
+    // ND > 1 (several slices per wavefront sharing guide pixel and statistics) was measured and rejected: <CPL,ND> =
+    // <2,1> 6.2 ms, <2,2> 7.4, <1,2> 7.5, <1,4> 9.7 -- the extra registers cost more occupancy than the traffic saves.
+    return launch_walk_t<NP, 2, ND>(s, src, dst, H, W, k, n);
 }
 
 }  // namespace
@@ -431,42 +437,61 @@ int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, 
 
 int launch_guided(hipStream_t s, const GuidedLaunch& a)
 {
-    GuideAcc g;
-    g.A = a.guideA; g.B = a.guideB; g.scales = a.gscales; g.scale_stride = a.guide_per_slice ? 1 : 0;
-    g.W = a.W; g.shiftA = a.shiftA; g.shiftB = a.shiftB; g.minD = a.minD;
     const int nstat = a.guide_per_slice ? a.n : 1;
     const float epsf = (float)a.eps;
+    const bool shifted = a.shiftA != 0 || a.shiftB != 0 || a.guide_per_slice;
     int rc;
-    if (a.C == 3) {
-        // 1. guide statistics (once: the guide does not depend on the slice)  2. a, b  3. q
-        StatsSrc<3, 0> ss{g};
+    if (a.C == 3 && !shifted) {
+        // GuidedF_2 / 3-channel getGuidedFilter: the guide does not depend on the slice.
+        // 1. guide statistics, once   2. a, b   3. q
+        GuideAccT<false> g{a.guideA, a.guideB, a.gscales, 0, a.W, 0, 0, a.minD};
+        StatsSrc<3, 0, false> ss{g};
         StatsDst<3, 0> sd{a.stats, a.H, a.W, epsf};
-        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
+        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, 1);
         if (rc != ASW_OK) return rc;
-        ABSrc<3> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3> dst{a.stats, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
+        ABSrc<3, false> src{g, a.P, a.pscales, a.H, a.W};
+        ABDst<3, false> dst{a.stats, a.ab, a.H, a.W};
         rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
-        QDst<3> qd{g, a.q, a.H, a.W};
+        QDst<3, false> qd{g, a.q, a.H, a.W};
         return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
-    } else {
-        StatsSrc<6, 0> s0{g};
-        StatsDst<6, 0> d0{a.stats, a.H, a.W, epsf};
-        rc = launch_walk<6>(s, s0, d0, a.H, a.W, a.r, nstat);
-        if (rc != ASW_OK) return rc;
-        StatsSrc<6, 1> s1{g};
-        StatsDst<6, 1> d1{a.stats, a.H, a.W, epsf};
-        rc = launch_walk<6>(s, s1, d1, a.H, a.W, a.r, nstat);
-        if (rc != ASW_OK) return rc;
-        ABSrc<6> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<6> dst{a.stats, a.ab, a.H, a.W, a.guide_per_slice ? 1 : 0};
-        rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
-        if (rc != ASW_OK) return rc;
-        QSrc<6> qs{a.ab, a.H, a.W};
-        QDst<6> qd{g, a.q, a.H, a.W};
-        return launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);
     }
+    GuideAccT<true> g{a.guideA, a.guideB, a.gscales, a.guide_per_slice ? 1 : 0, a.W, a.shiftA, a.shiftB, a.minD};
+    if (a.C == 3) {
+        StatsSrc<3, 0, true> ss{g};
+        StatsDst<3, 0> sd{a.stats, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
+        ABSrc<3, true> src{g, a.P, a.pscales, a.H, a.W};
+        ABDst<3, true> dst{a.stats, a.ab, a.H, a.W};
+        rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
+        if (rc != ASW_OK) return rc;
+        QSrc<3> qs{a.ab, a.H, a.W};
+        QDst<3, true> qd{g, a.q, a.H, a.W};
+        return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
+    }
+    // 6-channel guide (GuidedF: statistics per slice; public getGuidedFilter: one slice)
+    StatsSrc<6, 0, true> s0{g};
+    StatsDst<6, 0> d0{a.stats, a.H, a.W, epsf};
+    rc = launch_walk<6>(s, s0, d0, a.H, a.W, a.r, nstat);
+    if (rc != ASW_OK) return rc;
+    StatsSrc<6, 1, true> s1{g};
+    StatsDst<6, 1> d1{a.stats, a.H, a.W, epsf};
+    rc = launch_walk<6>(s, s1, d1, a.H, a.W, a.r, nstat);
+    if (rc != ASW_OK) return rc;
+    ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
+    if (a.guide_per_slice) {
+        ABDst<6, true> dst{a.stats, a.ab, a.H, a.W};
+        rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
+    } else {
+        ABDst<6, false> dst{a.stats, a.ab, a.H, a.W};
+        rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
+    }
+    if (rc != ASW_OK) return rc;
+    QSrc<6> qs{a.ab, a.H, a.W};
+    QDst<6, true> qd{g, a.q, a.H, a.W};
+    return launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);
 }
 
 // interleaved C-channel 8U image -> BGRX word planes (channels 3w..3w+2 in plane w)
