@@ -25,7 +25,7 @@ __all__ = [
     "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
     "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
     "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
-    "stereoMatchingBatch",
+    "stereoMatchingBatch", "computeAdaptiveWeight_BLO1",
     "AswError",
 ]
 
@@ -173,6 +173,11 @@ class Context:
                                         minDisparity=186, numDisparity=144, return_cost_volume=False):
         return self._aggregate(self._lib.asw_aggregate_guided2, "asw_aggregate_guided2", numDisparity, leftImg, rightImg,
                                (int(dispType), float(eps), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeAdaptiveWeight_BLO1(self, leftImg, rightImg, dispType=DISPARITY_LEFT, sampleRateR=10, winSize=35,
+                                   minDisparity=186, numDisparity=144, return_cost_volume=False):
+        return self._aggregate(self._lib.asw_aggregate_blo1, "asw_aggregate_blo1", numDisparity, leftImg, rightImg,
+                               (int(dispType), float(sampleRateR), winSize, minDisparity, numDisparity), return_cost_volume)
 
     def computeAdaptiveWeight_WeightedMedian(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=35,
                                              sampleRateS=10, sampleRateR=10, minDisparity=186, numDisparity=144,
@@ -344,4 +349,5 @@ getGuidedFilter = _bind("getGuidedFilter")
 computeAdaptiveWeight_GuidedF = _bind("computeAdaptiveWeight_GuidedF")
 computeAdaptiveWeight_GuidedF_2 = _bind("computeAdaptiveWeight_GuidedF_2")
 computeAdaptiveWeight_WeightedMedian = _bind("computeAdaptiveWeight_WeightedMedian")
+computeAdaptiveWeight_BLO1 = _bind("computeAdaptiveWeight_BLO1")
 winnerTakeAll = _bind("winnerTakeAll")

@@ -282,6 +282,7 @@ struct MatchParams {
     double gamma_c = 30, gamma_g = 20;  // M.cpp:58
     double eps = 1e-6;                  // M.cpp:73,76
     double rate_s = 10, rate_r = 10;    // M.cpp:82
+    double blo_rate_r = 0.015;          // M.cpp:70
 };
 
 static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
@@ -528,6 +529,65 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     return ASW_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// O(1)-bilateral ASW: computeAdaptiveWeight_BLO1 (M.cpp:2505-2725)
+// ------------------------------------------------------------------------------------------
+static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+{
+    if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // getCostSAD_d -> Mat(), M.cpp:2458-2462
+    if (f->channels != 3 && f->channels != 1) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    // the reference indexes setsJB_ks_ds_x[key][offset] with the ABSOLUTE offset (M.cpp:2659): out of range unless 0
+    if (mp.minD != 0) return ASW_ERR_BAD_ARGUMENT;
+    if (mp.win < 1 || mp.win > 64) return ASW_ERR_BAD_ARGUMENT;
+    const int step = (int)(256 * mp.blo_rate_r);  // M.cpp:2550
+    if (step <= 0) return ASW_ERR_BAD_ARGUMENT;   // the reference's key loop would not terminate
+    const int H = f->rows, W = f->cols, n = mp.numD;
+    const size_t plane = (size_t)H * W;
+    std::vector<int> keys;
+    for (int i = 0; i < 256; i += step) keys.push_back(i);  // M.cpp:2551-2556
+    if (keys.back() != 255) keys.push_back(255);            // M.cpp:2557-2560
+    const int nk = (int)keys.size();
+    DevBuf& gl = ctx->buf("grayL");
+    DevBuf& gr = ctx->buf("grayR");
+    DevBuf& raw = ctx->buf("g_raw");
+    DevBuf& dk = ctx->buf("blo_keys");
+    DevBuf& bM = ctx->buf("blo_bM");
+    DevBuf& lo = ctx->buf("blo_lo");
+    DevBuf& hi = ctx->buf("blo_hi");
+    ASW_TRY(gl.ensure(plane));
+    ASW_TRY(gr.ensure(plane));
+    ASW_TRY(raw.ensure(plane * n * 4));
+    ASW_TRY(dk.ensure((size_t)nk * sizeof(int)));
+    ASW_TRY(bM.ensure(plane * nk * 4));
+    ASW_TRY(lo.ensure(plane * n * 4));
+    ASW_TRY(hi.ensure(plane * n * 4));
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = 0;
+    if (keep_volume) {
+        ASW_TRY(f->vol.ensure(plane * n * 4));
+        f->vol_floats = plane * n;
+    }
+    ASW_HIP_TRY(hipMemcpyAsync(dk.p, keys.data(), (size_t)nk * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (f->channels == 3) {  // M.cpp:2514-2521
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
+    } else {
+        ASW_HIP_TRY(hipMemcpyAsync(gl.p, f->L.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
+        ASW_HIP_TRY(hipMemcpyAsync(gr.p, f->R.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ASW_TRY(launch_cost_sad(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, n,
+                            raw.as<float>()));  // M.cpp:2529-2547
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ASW_TRY(launch_blo1(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), raw.as<float>(), dk.as<int>(), nk, step, H, W,
+                        mp.disparity_type, mp.win, n, bM.as<float>(), lo.as<float>(), hi.as<float>(),
+                        keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `keys` (host) must outlive the async copy
+    ctx->timing.aggregate_launches = 3;
+    return ASW_OK;
+}
+
 static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume)
 {
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
@@ -537,6 +597,7 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     switch (algorithm) {  // M.cpp:49-87
     case ASW_ALG_ADAPTIVE_WEIGHT: rc = run_bilateral(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC: rc = run_geodesic(ctx, f, mp, keep_volume); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_BLO1: rc = run_blo1(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, false); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, true); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN: rc = run_wmedian(ctx, f, mp, keep_volume); break;
@@ -836,6 +897,16 @@ extern "C" int asw_geodesic_dist(asw_ctx* ctx, const asw_image* img, float* out,
     ASW_HIP_TRY(hipMemcpyAsync(out, wo.p, plane * cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
+}
+
+extern "C" int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                  int disparity_type, double sample_rate_r, int win_size, int min_disparity,
+                                  int num_disparity, float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    mp.blo_rate_r = sample_rate_r;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BLO1, mp, cost_volume_out);
 }
 
 extern "C" int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,

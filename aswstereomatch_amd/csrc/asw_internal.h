@@ -135,3 +135,7 @@ int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, 
                       float* out);
 int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
                    int max_off, float* out);
+
+// ---- O(1)-bilateral ASW (BLO1), k_guided.hip ----
+int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, const int* keys, int nk, int step, int H,
+                int W, int disp_type, int win, int numD, float* bM, float* lo, float* hi, float* vol, float* disp);

@@ -205,6 +205,15 @@ inline AswMat computeAdaptiveWeight_geodesic(AswMat leftImg, AswMat rightImg, Di
     }, "computeAdaptiveWeight_geodesic");
 }
 
+// M.h:157-159
+inline AswMat computeAdaptiveWeight_BLO1(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, double sampleRateR = 10,
+                                         int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_blo1(c, l, r, o, (int)dispType, sampleRateR, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_BLO1");
+}
+
 // M.h:165
 inline AswMat getGuidedFilter(AswMat guidedImg, AswMat inputP, int r, double eps)
 {

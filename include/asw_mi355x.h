@@ -30,7 +30,7 @@ typedef enum asw_status {
     ASW_OK = 0,
     ASW_ERR_SIZE_MISMATCH = 1,      /* M.cpp:217-220, 313-316, 430-433: silent return          */
     ASW_ERR_EVEN_WINDOW = 2,        /* M.cpp:654-657, 1440-1443, 2458-2462, 3238-3241: Mat()  */
-    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,3,5,6,9,11)      */
+    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,3,5,9,11)        */
     ASW_ERR_UNSUPPORTED_LAYOUT = 4, /* where the reference throws cv::Exception (SURVEY B-7)  */
     ASW_ERR_HIP = 5,                /* a HIP runtime call or kernel launch failed             */
     ASW_ERR_ALLOC = 6,
@@ -123,6 +123,11 @@ int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* r
 int asw_aggregate_guided2(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
                           float* cost_volume_out);
+/* computeAdaptiveWeight_BLO1, M.h:157-159, M.cpp:2505-2725 (min_disparity must be 0: the reference indexes its
+ * per-key slices with the absolute offset) */
+int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                       int disparity_type, double sample_rate_r, int win_size, int min_disparity, int num_disparity,
+                       float* cost_volume_out);
 /* computeAdaptiveWeight_WeightedMedian, M.h:179-182, M.cpp:3228-3383 */
 int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,

@@ -973,6 +973,98 @@ int orc_asw_wmedian(const uint8_t* L, const uint8_t* R, int H, int W, int disp_t
     return ORC_OK;
 }
 
+
+/* ---------------------------------------------------------------------------------------
+ * O(1)-bilateral ASW, computeAdaptiveWeight_BLO1, M.cpp:2505-2725
+ * Quirks reproduced: weights are |I - k| (a distance, not a similarity); abs(img - k) is folded by
+ * MatExpr into absdiff(img, k); the right view is shifted by the loop INDEX i while costs_ds[i] is
+ * the cost at disparity minD+i; the normaliser box(M) is taken from the LAST disparity only
+ * (M.cpp:2582 is outside the i-loop) and divides every slice; the interpolation weights are
+ * swapped ((cur-lower) multiplies the LOWER slice, M.cpp:2659-2660).  The WTA indexes the per-key
+ * vectors with the ABSOLUTE offset (M.cpp:2659), which is out of range unless minDisparity == 0:
+ * only minDisparity == 0 is accepted.
+ * ------------------------------------------------------------------------------------- */
+int orc_asw_blo1(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, double sampleRateR, int win, int minD,
+                 int numD, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* getCostSAD_d returns Mat(), M.cpp:2458-2462 */
+    if (minD != 0) return 7;                       /* see header: UB in the reference */
+    const int step = (int)(256 * sampleRateR);     /* M.cpp:2550 */
+    if (step <= 0) return 7;                       /* the reference's key loop would never terminate */
+    const size_t N = (size_t)H * W;
+    int keys[257], nk = 0;
+    for (int i = 0; i < 256; i += step) keys[nk++] = i; /* M.cpp:2551-2556 */
+    if (keys[nk - 1] != 255) keys[nk++] = 255;          /* M.cpp:2557-2560 */
+    uint8_t* gl = (uint8_t*)malloc(N);
+    uint8_t* gr = (uint8_t*)malloc(N);
+    float* costs = (float*)malloc((size_t)numD * N * sizeof(float));
+    float* JB = (float*)malloc((size_t)nk * numD * N * sizeof(float));
+    if (!gl || !gr || !costs || !JB) { free(gl); free(gr); free(costs); free(JB); return ORC_ERR_ALLOC; }
+    orc_bgr2gray(L, H, W, gl);
+    orc_bgr2gray(R, H, W, gr);
+    int rc = orc_cost_sad(L, R, H, W, disp_type, win, minD, numD, costs); /* M.cpp:2529-2547 */
+    if (rc != ORC_OK) { free(gl); free(gr); free(costs); free(JB); return rc; }
+    int key_index[256];
+    for (int i = 0; i < 256; i++) key_index[i] = -1;
+    for (int ki = 0; ki < nk; ki++) key_index[keys[ki]] = ki;
+
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int ki = 0; ki < nk; ki++) {
+        const int k = keys[ki];
+        float* M = (float*)malloc(N * sizeof(float));
+        float* J = (float*)malloc(N * sizeof(float));
+        float* bM = (float*)malloc(N * sizeof(float));
+        for (int i = 0; i < numD; i++) {
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    int a, b;
+                    if (disp_type == DISPARITY_LEFT) { /* M.cpp:2571-2580 */
+                        a = absdiff_u8(gl[(size_t)y * W + x], k);
+                        b = absdiff_u8(gr[(size_t)y * W + reflect_idx(x - i, W)], k);
+                    } else { /* M.cpp:2599-2608 */
+                        b = absdiff_u8(gr[(size_t)y * W + x], k);
+                        a = absdiff_u8(gl[(size_t)y * W + reflect_idx(x + i, W)], k);
+                    }
+                    float m = (float)b * (float)a; /* M_k_y_r.mul(M_k_y_l) */
+                    M[(size_t)y * W + x] = m;
+                    J[(size_t)y * W + x] = m * costs[(size_t)i * N + (size_t)y * W + x];
+                }
+            box_filter_plane(J, 1, JB + ((size_t)ki * numD + i) * N, 1, H, W, win); /* M.cpp:2578 */
+        }
+        box_filter_plane(M, 1, bM, 1, H, W, win); /* M.cpp:2582: M of the LAST disparity */
+        for (int i = 0; i < numD; i++) {
+            float* jb = JB + ((size_t)ki * numD + i) * N;
+            for (size_t p = 0; p < N; p++) jb[p] = jb[p] / bM[p]; /* M.cpp:2588, IEEE f32 division */
+        }
+        free(M); free(J); free(bM);
+    }
+
+    const uint8_t* ref = disp_type == DISPARITY_LEFT ? gl : gr;
+    for (size_t p = 0; p < N; p++) {
+        double best = DBL_MAX;
+        float bd = 0.0f;
+        const int cur = ref[p];
+        for (int off = 0; off < numD; off++) { /* min_offset..max_offset with minD == 0 */
+            double c;
+            if (key_index[cur] < 0) { /* M.cpp:2650-2661 */
+                int lower = cur / step * step, upper = lower + step;
+                if (upper > 255) upper = 255;
+                float lo = JB[((size_t)key_index[lower] * numD + off) * N + p];
+                float hi = JB[((size_t)key_index[upper] * numD + off) * N + p];
+                float t = (float)(cur - lower) * lo + (float)(upper - cur) * hi;
+                c = (double)t;
+            } else {
+                c = (double)JB[((size_t)key_index[cur] * numD + off) * N + p];
+            }
+            if (vol) vol[(size_t)off * N + p] = (float)c;
+            if (c < best) { best = c; bd = (float)off; }
+        }
+        disp[p] = bd;
+    }
+    free(gl); free(gr); free(costs); free(JB);
+    return ORC_OK;
+}
+
 /* ---------------------------------------------------------------------------------------
  * stereoMatching selector, M.cpp:46-88, with the literals it hard-codes.
  * ------------------------------------------------------------------------------------- */
@@ -982,6 +1074,7 @@ int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int di
     switch (algorithm) {
     case 2: return orc_asw_classic(L, R, H, W, 30, 20, disparity_type, win, minD, numD, disp, NULL);  /* M.cpp:58 */
     case 4: return orc_asw_geodesic(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:64 */
+    case 6: return orc_asw_blo1(L, R, H, W, disparity_type, 0.015, win, minD, numD, disp, NULL);       /* M.cpp:70 */
     case 7: return orc_asw_guided(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);      /* M.cpp:73 */
     case 8: return orc_asw_guided2(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);     /* M.cpp:76 */
     case 10: return orc_asw_wmedian(L, R, H, W, disparity_type, win, 10, 10, minD, numD, disp, NULL);  /* M.cpp:82 */

@@ -207,6 +207,10 @@ def asw_guided(L, R, disp_type=0, eps=1e-6, win=15, minD=0, numD=64, want_vol=Fa
     return _agg(lib().orc_asw_guided, L, R, numD, want_vol, disp_type, C.c_double(eps), win, minD, numD)
 
 
+def asw_blo1(L, R, disp_type=0, sampleRateR=0.015, win=15, minD=0, numD=64, want_vol=False):
+    return _agg(lib().orc_asw_blo1, L, R, numD, want_vol, disp_type, C.c_double(sampleRateR), win, minD, numD)
+
+
 def wm_color_weight(d0, d1, d2, rateR=10.0):
     return float(lib().orc_wm_color_weight(int(d0), int(d1), int(d2), C.c_double(rateR)))
 

@@ -37,7 +37,7 @@ def test_enum_values_match_reference():
     hdr = open(os.path.join(ROOT, "include", "asw_mi355x.h")).read()
     for name, val in [("ASW_ALG_ADAPTIVE_WEIGHT", 2), ("ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC", 4),
                       ("ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER", 7), ("ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2", 8),
-                      ("ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN", 10), ("ASW_ALG_NCC", 11)]:
+                      ("ASW_ALG_ADAPTIVE_WEIGHT_BLO1", 6), ("ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN", 10), ("ASW_ALG_NCC", 11)]:
         assert re.search(r"%s\s*=\s*%d\b" % (name, val), hdr), name
 
 

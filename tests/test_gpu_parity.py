@@ -109,7 +109,7 @@ def test_error_behaviour(ctx):
     assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
     assert ctx.stereoMatching(L, R[:, :30], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) is None
     assert asw.last_status() == asw.ERR_SIZE_MISMATCH
-    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, A.ADAPTIVE_WEIGHT_BLO1,
+    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID,
                 A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.NCC):
         with pytest.raises(asw.AswError) as e:
             ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
@@ -307,3 +307,32 @@ def test_right_recovers_shift(ctx):
     for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GEODESIC):
         d = ctx.stereoMatching(L, R, RIGHT, alg, 7, 0, 8)
         assert (d[8:-8, 8:-16] == d0).all(), alg
+
+
+# ---------------------------------------------------------------- O(1)-bilateral ASW (BLO1), SURVEY 8f row f1
+@pytest.mark.parametrize("H,W,win,numD,dt,rate,seed", [(24, 40, 5, 8, 0, 0.015, 3), (40, 150, 15, 12, 0, 0.015, 4), (30, 100, 7, 9, 1, 0.015, 5),
+                                                       (20, 64, 5, 6, 0, 0.04, 6), (1, 1, 3, 2, 0, 0.015, 7), (5, 129, 7, 20, 1, 0.1, 8)])
+def test_blo1_parity(ctx, oracle, H, W, win, numD, dt, rate, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_blo1(L, R, dt, rate, win, 0, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_BLO1(L, R, dt, rate, win, 0, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD, H, W)
+    fin = np.isfinite(v_want)
+    assert np.array_equal(fin, np.isfinite(v_got)) and np.array_equal(np.isnan(v_want), np.isnan(v_got))
+    assert np.allclose(v_got[fin], v_want[fin], rtol=1e-4, atol=0)   # float cost volume within 1e-4 (relative)
+    assert np.array_equal(d_got, d_want)
+    if rate == 0.015:
+        assert np.array_equal(ctx.stereoMatching(L, R, dt, A.ADAPTIVE_WEIGHT_BLO1, win, 0, numD), d_want)  # selector literal M.cpp:70
+
+
+def test_blo1_reference_limits(ctx):
+    L, R, _ = make_pair(16, 32, 4, seed=1)
+    assert ctx.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.015, 6, 0, 4) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
+    with pytest.raises(asw.AswError) as e:   # absolute-offset indexing of the reference: only minDisparity == 0 is defined
+        ctx.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.015, 5, 2, 4)
+    assert e.value.status == asw.ERR_BAD_ARGUMENT
+    with pytest.raises(asw.AswError):        # 256*rate < 1: the reference's key loop never terminates
+        ctx.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.001, 5, 0, 4)
+    d0 = 5
+    Ls, Rs = shifted_pair(40, 64, d0)
+    assert (ctx.stereoMatching(Ls, Rs, LEFT, A.ADAPTIVE_WEIGHT_BLO1, 7, 0, 8)[8:-8, 16:-8] == d0).all()

@@ -289,5 +289,17 @@ def test_selector_literals(oracle):
                         (10, lambda: oracle.asw_wmedian(L, R, 0, 5, 10, 10, 0, 6))]:
         rc, d = oracle.stereo_matching(L, R, 0, alg, 5, 0, 6)
         assert rc == 0 and np.array_equal(d, direct()[1]), alg
-    for alg in (0, 1, 3, 5, 6, 9, 11):
+    rc, d = oracle.stereo_matching(L, R, 0, 6, 5, 0, 6)
+    assert rc == 0 and np.array_equal(d, oracle.asw_blo1(L, R, 0, 0.015, 5, 0, 6)[1])
+    for alg in (0, 1, 3, 5, 9, 11):
         assert oracle.stereo_matching(L, R, 0, alg, 5, 0, 6)[0] == oracle.ERR_UNSUPPORTED_METHOD
+
+
+def test_blo1_quirks(oracle):
+    # keys 0,3,...,255 for sampleRateR = 0.015 (M.cpp:2550-2560); identical images at d=0 cost 0 everywhere
+    L, R, _ = make_pair(16, 24, 4, seed=2, block=8)
+    rc, d, v = oracle.asw_blo1(L, L.copy(), 0, 0.015, 5, 0, 3, want_vol=True)
+    assert rc == 0 and np.nanmax(np.abs(v[0])) == 0.0 and (d == 0).all()
+    assert oracle.asw_blo1(L, R, 0, 0.015, 4, 0, 3)[0] == oracle.ERR_EVEN_WINDOW
+    assert oracle.asw_blo1(L, R, 0, 0.015, 5, 1, 3)[0] == 7       # absolute-offset indexing: minDisparity must be 0
+    assert oracle.asw_blo1(L, R, 0, 0.001, 5, 0, 3)[0] == 7       # step 0: the reference would loop forever
