@@ -79,57 +79,83 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
 template <int LM>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v)
 {
-    if constexpr (LM == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
-    else if constexpr (LM == 2) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    else if constexpr (LM == 8) return dpp_mov<0x128>(v);  // row_ror:8 == xor 8 inside a 16-lane row
-    else if constexpr (LM == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
-    else if constexpr (LM == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1f);
+    if constexpr (LM == 1) return dpp_mov<0xB1>(v);         // quad_perm [1,0,3,2]
+    else if constexpr (LM == 2) return dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    else if constexpr (LM == 3) return dpp_mov<0x1B>(v);    // quad_perm [3,2,1,0]
+    else if constexpr (LM == 7) return dpp_mov<0x141>(v);   // row_half_mirror
+    else if constexpr (LM == 15) return dpp_mov<0x140>(v);  // row_mirror
+    else if constexpr (LM == 8) return dpp_mov<0x128>(v);   // row_ror:8 == xor 8 inside a 16-lane row
+    else if constexpr (LM == 4 || LM == 16 || LM == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (LM << 10) | 0x1f);
     else return (uint32_t)__shfl_xor((int)v, LM);
 }
 
-template <int K, int J>
-__device__ __forceinline__ void bitonic_step(uint32_t (&key)[4], int lane)
+// Sorting network: merges of size K = 2, 4, ..., 256 over element e = lane*4 + r.  Every merge starts with a
+// MIRROR step (partner e ^ (K-1)) and continues with half-cleaners (partner e ^ j): all comparisons then sort
+// ascending -- the lower index takes the minimum -- so intra-lane exchanges are a bare v_min/v_max pair and
+// cross-lane ones select with one of six loop-invariant lane masks (bit 0..5 of the lane id).
+struct LaneMasks { uint32_t m[6]; };  // m[b] = all ones where bit b of the lane id is clear (loop-invariant VGPRs)
+
+template <int LM, int RX, int BITLOG>  // partner = (lane ^ LM, r ^ RX); the lane with bit BITLOG clear is the lower one
+__device__ __forceinline__ void cross_step(uint32_t (&key)[4], const LaneMasks& lm)
 {
-    if constexpr (J >= 4) {
-        constexpr int LM = J >> 2;
-        const bool up = ((lane * 4) & K) == 0;  // K >= 8: direction depends on the lane only
-        const bool lower = (lane & LM) == 0;
-        const bool take_min = (up == lower);    // loop invariant: lives in an SGPR pair
+    const bool lower = lm.m[BITLOG] != 0u;
+    uint32_t o[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t o = lane_xor<LM>(key[r]);
-            const uint32_t mn = min(key[r], o), mx = max(key[r], o);
-            key[r] = take_min ? mn : mx;
-        }
-    } else {
+    for (int r = 0; r < 4; r++) o[r] = lane_xor<LM>(key[r ^ RX]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int q = r ^ J;
-            if (q > r) {
-                const bool up = ((lane * 4 + r) & K) == 0;
-                const uint32_t a = key[r], b = key[q];
-                const uint32_t mn = min(a, b), mx = max(a, b);
-                key[r] = up ? mn : mx;
-                key[q] = up ? mx : mn;
-            }
+    for (int r = 0; r < 4; r++) {
+        const uint32_t mn = min(key[r], o[r]), mx = max(key[r], o[r]);
+        key[r] = lower ? mn : mx;  // lower lane keeps the minimum, upper lane the maximum
+    }
+}
+
+template <int RX>  // intra-lane: pairs (r, r ^ RX)
+__device__ __forceinline__ void local_step(uint32_t (&key)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int q = r ^ RX;
+        if (q > r) {
+            const uint32_t a = key[r], b = key[q];
+            key[r] = min(a, b);
+            key[q] = max(a, b);
         }
     }
 }
 
-template <int K, int J>
-__device__ __forceinline__ void bitonic_merge(uint32_t (&key)[4], int lane)
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+template <int J>  // half-cleaner steps j = J, J/2, ..., 1 (element distance)
+__device__ __forceinline__ void half_cleaners(uint32_t (&key)[4], const LaneMasks& lm)
 {
-    bitonic_step<K, J>(key, lane);
-    if constexpr (J > 1) bitonic_merge<K, J / 2>(key, lane);
+    if constexpr (J >= 4) {
+        cross_step<J / 4, 0, ilog2(J / 4)>(key, lm);
+        half_cleaners<J / 2>(key, lm);
+    } else if constexpr (J >= 1) {
+        local_step<J>(key);
+        if constexpr (J > 1) half_cleaners<J / 2>(key, lm);
+    }
 }
 
 template <int K>
-__device__ __forceinline__ void bitonic_sort(uint32_t (&key)[4], int lane)
+__device__ __forceinline__ void merge_sorted_halves(uint32_t (&key)[4], const LaneMasks& lm)
 {
-    if constexpr (K > 2) bitonic_sort<K / 2>(key, lane);
-    bitonic_merge<K, K / 2>(key, lane);
+    if constexpr (K == 2) {
+        local_step<1>(key);
+    } else if constexpr (K == 4) {
+        local_step<3>(key);  // mirror inside the lane: (0,3) (1,2)
+        half_cleaners<1>(key, lm);
+    } else {
+        cross_step<K / 4 - 1, 3, ilog2(K / 8)>(key, lm);  // mirror: lane ^ (K/4-1), register ^ 3
+        half_cleaners<K / 4>(key, lm);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void bitonic_sort(uint32_t (&key)[4], const LaneMasks& lm)
+{
+    if constexpr (K > 2) bitonic_sort<K / 2>(key, lm);
+    merge_sorted_halves<K>(key, lm);
 }
 
 constexpr int WM_WAVES = 4;
@@ -148,17 +174,23 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
     const int n = win * win, h = win / 2, Wb = W + max_off;
     const size_t plane = (size_t)H * W;
 
+    LaneMasks lm;
+#pragma unroll
+    for (int b = 0; b < 6; b++) lm.m[b] = (lane & (1 << b)) ? 0u : 0xffffffffu;
+
     float wl[4];
-    int off[4];  // offset of the element's cost sample inside a cost plane (REFLECT-padded window, M.cpp:665,3273)
-    bool valid[4];
+    int off[4];   // offset of the element's cost sample inside a cost plane (REFLECT-padded window, M.cpp:665,3273)
+    int ee[4];    // window index, clamped for the padding slots (their loads are discarded)
+    uint32_t padkey[4];  // 0 for real elements, all ones for padding slots (sorts last, weight 0)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int e = lane * 4 + r;
-        valid[r] = e < n;
-        const int ee = valid[r] ? e : 0;
-        const int j = ee / win, i = ee - j * win;
+        const bool valid = e < n;
+        ee[r] = valid ? e : 0;
+        padkey[r] = valid ? 0u : 0xffffffffu;
+        const int j = ee[r] / win, i = ee[r] - j * win;
         off[r] = reflect_idx(y + j - h, H) * W + reflect_idx(x + i - h, W);
-        wl[r] = valid[r] ? wLd[pix * n + ee] : 0.0f;
+        wl[r] = valid ? wLd[pix * n + ee[r]] : 0.0f;
     }
 
     for (int d = 0; d < numD; d++) {
@@ -171,13 +203,8 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int e = lane * 4 + r;
-            if (valid[r]) {
-                w[r] = wl[r] * wr[e];  // (wL .mul wd) .mul wR, f32
-                key[r] = ((__float_as_uint(cp[off[r]]) - COST_BASE_BITS) << 8) | (uint32_t)e;
-            } else {
-                w[r] = 0.0f;
-                key[r] = 0xffffffffu;
-            }
+            w[r] = wl[r] * wr[ee[r]];  // (wL .mul wd) .mul wR, f32 (0 for padding slots: wl = 0)
+            key[r] = (((__float_as_uint(cp[off[r]]) - COST_BASE_BITS) << 8) | (uint32_t)e) | padkey[r];
             s_loc += (double)w[r];
             sW[wv][e] = w[r];
         }
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         const double half = tot / 2;
 
-        bitonic_sort<256>(key, lane);
+        bitonic_sort<256>(key, lm);
 
         // weights in sorted order, inclusive prefix sums in f64
         double pre[4];

@@ -34,7 +34,11 @@ def main():
                      ("geodesic", lambda: O.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
                      ("guided", lambda: O.asw_guided(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided2", lambda: O.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
-                     ("wmedian", lambda: O.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True))]:
+                     ("wmedian", lambda: O.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True)),
+                     ("blo1", lambda: O.asw_blo1(L, R, 0, 0.015, WIN, 0, D, want_vol=True)),
+                     ("classic_right", lambda: O.asw_classic(L, R, 30, 20, 1, WIN, 0, D, want_vol=True)),
+                     ("geodesic_right", lambda: O.asw_geodesic(L, R, 1, WIN, 0, D, want_vol=True)),
+                     ("guided_right", lambda: O.asw_guided(L, R, 1, 1e-6, WIN, 0, D, want_vol=True))]:
         rc, disp, vol = fn()
         assert rc == 0
         out[name + "_disp"] = disp

@@ -26,7 +26,11 @@ def test_oracle_reproduces_golden(oracle, gold):
                      ("geodesic", lambda: oracle.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
                      ("guided", lambda: oracle.asw_guided(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided2", lambda: oracle.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
-                     ("wmedian", lambda: oracle.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True))]:
+                     ("wmedian", lambda: oracle.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True)),
+                     ("blo1", lambda: oracle.asw_blo1(L, R, 0, 0.015, WIN, 0, D, want_vol=True)),
+                     ("classic_right", lambda: oracle.asw_classic(L, R, 30, 20, 1, WIN, 0, D, want_vol=True)),
+                     ("geodesic_right", lambda: oracle.asw_geodesic(L, R, 1, WIN, 0, D, want_vol=True)),
+                     ("guided_right", lambda: oracle.asw_guided(L, R, 1, 1e-6, WIN, 0, D, want_vol=True))]:
         rc, disp, vol = fn()
         assert rc == 0 and np.array_equal(disp, gold[name + "_disp"]), name
         assert np.array_equal(vol, gold[name + "_vol"], equal_nan=True), name
@@ -63,4 +67,14 @@ def test_hip_reproduces_golden(gold):
         d, v = ctx.stereoMatching(L, R, LEFT, alg, WIN, 0, D, return_cost_volume=True)
         assert np.array_equal(d, gold[name + "_disp"]), name          # WTA index bit-exact
         assert np.abs(v - gold[name + "_vol"]).max() < 1e-4, name      # float cost volume within 1e-4 (north_star)
+    RIGHT = asw.DISPARITY_RIGHT
+    for name, alg in {"classic_right": A.ADAPTIVE_WEIGHT, "geodesic_right": A.ADAPTIVE_WEIGHT_GEODESIC}.items():
+        d, v = ctx.stereoMatching(L, R, RIGHT, alg, WIN, 0, D, return_cost_volume=True)
+        assert np.array_equal(d, gold[name + "_disp"]) and np.array_equal(v, gold[name + "_vol"], equal_nan=True), name
+    d, v = ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER, WIN, 0, D, return_cost_volume=True)
+    assert np.array_equal(d, gold["guided_right_disp"]) and np.abs(v - gold["guided_right_vol"]).max() < 1e-4
+    d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_BLO1, WIN, 0, D, return_cost_volume=True)
+    gv = gold["blo1_vol"]
+    fin = np.isfinite(gv)
+    assert np.array_equal(d, gold["blo1_disp"]) and np.allclose(v[fin], gv[fin], rtol=1e-4, atol=0)
     ctx.close()
