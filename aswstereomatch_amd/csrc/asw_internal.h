@@ -99,7 +99,6 @@ int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t*
                            int disp_type, uint32_t* ord_scratch, int* colmm_scratch /* 2W */, float2* scales /* numD */);
 
 // ---- box means / guided filter (k_guided.hip) ----
-int launch_box_filter(hipStream_t s, const float* in, float* out, int n, int H, int W, int k);
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost);
 struct GuidedLaunch {

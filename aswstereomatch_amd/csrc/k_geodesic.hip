@@ -163,8 +163,8 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     // LDS carve-up (sized on the host for DC = GDC).  The colour-L1 cost (<= 765) is kept as u16: 16 B per cell
     // at DC = 8 -> one ds_read_b128 per tap, and the whole workgroup needs 40 KB -> four workgroups per CU.
     uint16_t* sC = reinterpret_cast<uint16_t*>(smem);                            // [TR*LW][DC]
-    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);     // [GG][TH][TW+GDC-1]
-    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));  // [TR][LW]
+    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);     // [2][GG][TH][TW+GDC-1]
+    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + 2 * GG * TH * (TW + GDC - 1));  // [TR][LW]
     uint32_t* sR = sL + TR * LW;                                                 // [TR][RWmax]
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -203,53 +203,93 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     const float* myWR = sWR + ty * (TW + GDC - 1) + tx + (DC - 1);
     const int ntaps = win * win;
 
-    int j = 0, i = 0;  // window row / column of tap t (M.cpp:1481-1483), advanced without divisions
-    for (int g0 = 0; g0 < ntaps; g0 += GG) {
+    // Staging positions of the right-image weights (each is used by up to DC (pixel,d) pairs): pass A = (row ty,
+    // column tx), pass B = the DC-1 extra columns of the four rows (first TH*(DC-1) threads).  Column jj holds the
+    // weight window of right pixel xr = max(0, x - d) with jj = tx + (DC-1) - dd.
+    const int xrA = min(max(x0 - d0 - (DC - 1) + tx, 0), W - 1);
+    const uint16_t* pA = wR + (size_t)yc * W + (p.flip ? W - 1 - xrA : xrA);
+    float* dstA = sWR + ty * (TW + GDC - 1) + tx;
+    constexpr int NEXTRA = TH * (DC - 1);
+    const bool doB = (DC > 1) && tid < NEXTRA;
+    const int rowB = (DC > 1) ? min(tid / (DC > 1 ? DC - 1 : 1), TH - 1) : 0;
+    const int jjB = TW + tid - rowB * (DC - 1);
+    const int xrB = min(max(x0 - d0 - (DC - 1) + jjB, 0), W - 1);
+    const uint16_t* pB = wR + (size_t)min(y0 + rowB, H - 1) * W + (p.flip ? W - 1 - xrB : xrB);
+    float* dstB = sWR + rowB * (TW + GDC - 1) + jjB;
+
+    // window row / column of a tap (M.cpp:1481-1483), advanced without divisions; the mirrored problem reads the
+    // weight planes with reversed window columns
+    int js = 0, is = 0;  // staging cursor
+    int j = 0, i = 0;    // accumulation cursor
+    auto plane_of = [&](int tj, int ti) { return (size_t)(tj * win + (p.flip ? win - 1 - ti : ti)) * plane; };
+    constexpr int GSTR = GG * TH * (TW + GDC - 1);  // floats per staging buffer (two buffers: software pipeline)
+    float rA[GG], rB[GG], rW[GG];
+    auto fetch_group = [&](int g0) {  // loads only: weights of the taps g0 .. g0+GG-1 into registers
         const int ng = min(GG, ntaps - g0);
-        __syncthreads();
-        // right-image weights of the tile rows for xr = max(0, x - d): column jj = tx + (DC-1) - dd
-        for (int q = tid; q < ng * TH * SWR; q += 256) {
-            int tt = q / (TH * SWR), rem = q - tt * (TH * SWR);
-            int row = rem / SWR, jj = rem - row * SWR;
-            int xr = min(max(x0 - d0 - (DC - 1) + jj, 0), W - 1);
-            int yy = min(y0 + row, H - 1);
-            int tcell = g0 + tt;
-            if (p.flip) { int tj = tcell / win; tcell = tj * win + (win - 1 - (tcell - tj * win)); }  // reversed window column
-            sWR[(tt * TH + row) * (TW + GDC - 1) + jj] = (float)wR[(size_t)tcell * plane + (size_t)yy * W + (p.flip ? W - 1 - xr : xr)];
-        }
-        auto wl_cell = [&](int t, int tj, int ti) { return (size_t)(p.flip ? tj * win + (win - 1 - ti) : t) * plane; };
-        float wl_next = (float)myWL[wl_cell(g0, j, i)];
-        __syncthreads();
-        for (int tt = 0; tt < ng; tt++) {
-            const float wl = wl_next;
-            if (g0 + tt + 1 < ntaps) {  // next tap's weight in flight
-                const int ni = (i + 1 == win) ? 0 : i + 1, nj = (i + 1 == win) ? j + 1 : j;
-                wl_next = (float)myWL[wl_cell(g0 + tt + 1, nj, ni)];
-            }
-            const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
-            uint32_t cw[(DC + 1) / 2];
-            if constexpr (DC == 8) {
-                uint4 v = *reinterpret_cast<const uint4*>(cell);
-                cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-            } else if constexpr (DC == 4) {
-                uint2 v = *reinterpret_cast<const uint2*>(cell);
-                cw[0] = v.x; cw[1] = v.y;
-            } else if constexpr (DC == 2) {
-                cw[0] = *reinterpret_cast<const uint32_t*>(cell);
-            } else {
-                cw[0] = cell[0];
-            }
-            const float* wr = myWR + tt * TH * (TW + GDC - 1);
 #pragma unroll
-            for (int dd = 0; dd < DC; dd++) {
-                float c = (float)((cw[dd >> 1] >> (16 * (dd & 1))) & 0xffffu);
-                float ab = wl * wr[-dd];   // f32
-                float abc = ab * c;        // f32 (M.cpp:1488-1490)
-                num[dd] = num[dd] + (double)abc;
-                den[dd] = den[dd] + (double)ab;
+        for (int tt = 0; tt < GG; tt++) {
+            if (tt < ng) {
+                const size_t po = plane_of(js, is);
+                rA[tt] = (float)pA[po];
+                rB[tt] = doB ? (float)pB[po] : 0.0f;
+                rW[tt] = (float)myWL[po];  // this thread's own left-image weight
+                if (++is == win) { is = 0; js++; }
             }
-            if (++i == win) { i = 0; j++; }
         }
+    };
+    auto store_group = [&](int buf) {
+#pragma unroll
+        for (int tt = 0; tt < GG; tt++) {
+            dstA[buf * GSTR + tt * TH * (TW + GDC - 1)] = rA[tt];
+            if (doB) dstB[buf * GSTR + tt * TH * (TW + GDC - 1)] = rB[tt];
+        }
+    };
+    __syncthreads();  // cost tile complete, previous chunk's staging buffers free
+    fetch_group(0);
+    store_group(0);
+    float wlv[GG];
+#pragma unroll
+    for (int tt = 0; tt < GG; tt++) wlv[tt] = rW[tt];
+    __syncthreads();
+    int buf = 0;
+    for (int g0 = 0; g0 < ntaps; g0 += GG, buf ^= 1) {
+        const int ng = min(GG, ntaps - g0);
+        if (g0 + GG < ntaps) fetch_group(g0 + GG);  // next group's loads fly while this group is accumulated
+#pragma unroll
+        for (int tt = 0; tt < GG; tt++) {
+            if (tt < ng) {
+                const float wl = wlv[tt];
+                const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
+                uint32_t cw[(DC + 1) / 2];
+                if constexpr (DC == 8) {
+                    uint4 v = *reinterpret_cast<const uint4*>(cell);
+                    cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+                } else if constexpr (DC == 4) {
+                    uint2 v = *reinterpret_cast<const uint2*>(cell);
+                    cw[0] = v.x; cw[1] = v.y;
+                } else if constexpr (DC == 2) {
+                    cw[0] = *reinterpret_cast<const uint32_t*>(cell);
+                } else {
+                    cw[0] = cell[0];
+                }
+                const float* wr = myWR + buf * GSTR + tt * TH * (TW + GDC - 1);
+#pragma unroll
+                for (int dd = 0; dd < DC; dd++) {
+                    float c = (float)((cw[dd >> 1] >> (16 * (dd & 1))) & 0xffffu);
+                    float ab = wl * wr[-dd];   // f32
+                    float abc = ab * c;        // f32 (M.cpp:1488-1490)
+                    num[dd] = num[dd] + (double)abc;
+                    den[dd] = den[dd] + (double)ab;
+                }
+                if (++i == win) { i = 0; j++; }
+            }
+        }
+        if (g0 + GG < ntaps) {
+            store_group(buf ^ 1);  // that buffer was last read one iteration ago, before the barrier below
+#pragma unroll
+            for (int tt = 0; tt < GG; tt++) wlv[tt] = rW[tt];
+        }
+        __syncthreads();
     }
     if (x < W && y < H) {
 #pragma unroll
@@ -269,7 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     extern __shared__ __align__(16) unsigned char smem[];
     const int h = p.win / 2, TR = TH + 2 * h, LW = TW + 2 * h;
     float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);
-    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + GG * TH * (TW + GDC - 1));
+    uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + 2 * GG * TH * (TW + GDC - 1));
     const int tid = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     for (int i = tid; i < TR * LW; i += 256) {
         int r = i / LW, c = i - r * LW;
@@ -343,7 +383,7 @@ int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* img
 {
     GeoParams p{H, W, win, minD, nD, flip};
     const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
-    size_t lds = (size_t)TR * LW * GDC * 2 + (size_t)GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
+    size_t lds = (size_t)TR * LW * GDC * 2 + (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
     if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     if (lds > 64 * 1024)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_asw_geodesic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -380,14 +380,6 @@ struct PlaneDst {
         out[((size_t)k * H + y) * W + x] = m[0];
     }
 };
-struct PlaneSrc {
-    const float* in;
-    int H, W;
-    struct Raw { float v; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const { return Raw{in[((size_t)k * H + y) * W + x]}; }
-    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = r.v; }
-};
-
 template <int NP, int CPL, int ND, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
 {
@@ -548,13 +540,6 @@ __global__ __launch_bounds__(256) void k_blo1_wta(BloKeys K, const uint8_t* __re
 }
 
 }  // namespace
-
-int launch_box_filter(hipStream_t s, const float* in, float* out, int n, int H, int W, int k)
-{
-    PlaneSrc src{in, H, W};
-    PlaneDst dst{out, H, W};
-    return launch_walk<1>(s, src, dst, H, W, k, n);
-}
 
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost)

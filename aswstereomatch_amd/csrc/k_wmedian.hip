@@ -50,17 +50,6 @@ __global__ __launch_bounds__(256) void k_wm_weights(const uint8_t* __restrict__ 
     out[i] = w;
 }
 
-__device__ __forceinline__ uint32_t f2ord(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o)
-{
-    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __uint_as_float(u);
-}
-
 // ---- 32-bit sort keys ---------------------------------------------------------------------------
 // The TAD C+G cost with the method's literals (0.4, 10, 50; M.cpp:3250) is 0.6*cc + 0.4*cg with cc in [0,255]
 // and cg in [12700, 12700+8160]: every cost lies in [4096, 16384), i.e. its f32 bit pattern minus that of
