@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_planes_to_windows(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // aggregation
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 4, GDC = 8, GG = 5;  // tile, disparities per thread, taps per staging group
+constexpr int TW = 64, TH = 4, GDC = 16, GG = 5;  // tile, disparities per thread, taps per staging group
 
 struct GeoParams {
     int H, W, win, minD, nD;
@@ -261,7 +261,12 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
                 const float wl = wlv[tt];
                 const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
                 uint32_t cw[(DC + 1) / 2];
-                if constexpr (DC == 8) {
+                if constexpr (DC == 16) {
+                    uint4 v = *reinterpret_cast<const uint4*>(cell);
+                    uint4 u = *reinterpret_cast<const uint4*>(cell + 8);
+                    cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+                    cw[4] = u.x; cw[5] = u.y; cw[6] = u.z; cw[7] = u.w;
+                } else if constexpr (DC == 8) {
                     uint4 v = *reinterpret_cast<const uint4*>(cell);
                     cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
                 } else if constexpr (DC == 4) {
@@ -301,7 +306,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
                                                       const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
                                                       const uint16_t* __restrict__ wR, float* __restrict__ vol,
                                                       float* __restrict__ disp)
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     double bestE = 1.7976931348623157e308;
     float bestD = 0.0f;
     int c0 = 0;
-    for (; c0 + 8 <= p.nD; c0 += 8) geo_chunk<8>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    for (; c0 + 16 <= p.nD; c0 += 16) geo_chunk<16>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    if (p.nD - c0 >= 8) { geo_chunk<8>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 8; }
     if (p.nD - c0 >= 4) { geo_chunk<4>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
     if (p.nD - c0 >= 2) { geo_chunk<2>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
     if (p.nD - c0 >= 1) { geo_chunk<1>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
