@@ -145,14 +145,14 @@ __global__ __launch_bounds__(256) void k_planes_to_windows(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // aggregation
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 4, GDC = 16, GG = 5;  // tile, disparities per thread, taps per staging group
+constexpr int TW = 64, TH = 4, GG = 5;  // tile, taps per staging group; GDC = widest d-chunk of a kernel instance
 
 struct GeoParams {
     int H, W, win, minD, nD;
     int flip;  // 1: mirrored problem (DISPARITY_RIGHT): images / weight planes are read at W-1-x, window columns reversed
 };
 
-template <int DC>
+template <int DC, int GDC>
 __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __restrict__ imgR,
                                           const uint16_t* __restrict__ wL, const uint16_t* __restrict__ wR,
                                           float* __restrict__ vol, unsigned char* smem, int c0, double& bestE, float& bestD)
@@ -306,6 +306,7 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     }
 }
 
+template <int GDC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
                                                       const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
                                                       const uint16_t* __restrict__ wR, float* __restrict__ vol,
@@ -324,11 +325,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     double bestE = 1.7976931348623157e308;
     float bestD = 0.0f;
     int c0 = 0;
-    for (; c0 + 16 <= p.nD; c0 += 16) geo_chunk<16>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
-    if (p.nD - c0 >= 8) { geo_chunk<8>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 8; }
-    if (p.nD - c0 >= 4) { geo_chunk<4>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
-    if (p.nD - c0 >= 2) { geo_chunk<2>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
-    if (p.nD - c0 >= 1) { geo_chunk<1>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
+    if constexpr (GDC >= 16)
+        for (; c0 + 16 <= p.nD; c0 += 16) geo_chunk<16, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    for (; c0 + 8 <= p.nD; c0 += 8) geo_chunk<8, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    if (p.nD - c0 >= 4) { geo_chunk<4, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
+    if (p.nD - c0 >= 2) { geo_chunk<2, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
+    if (p.nD - c0 >= 1) { geo_chunk<1, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
     if (x < p.W && y < p.H) disp[(size_t)y * p.W + (p.flip ? p.W - 1 - x : x)] = bestD;
 }
@@ -384,17 +386,35 @@ int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, i
     return ASW_OK;
 }
 
+namespace {
+template <int GDC>
+size_t geo_lds_bytes(int win)
+{
+    const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
+    return (size_t)TR * LW * GDC * 2 + (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
+}
+template <int GDC>
+int launch_geo_t(hipStream_t s, const GeoParams& p, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
+                 const uint16_t* wR, float* vol, float* disp)
+{
+    const size_t lds = geo_lds_bytes<GDC>(p.win);
+    auto kern = k_asw_geodesic<GDC>;
+    if (lds > 64 * 1024)
+        ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, imgL, imgR, wL, wR, vol, disp);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+}  // namespace
+
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
                         int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp)
 {
     GeoParams p{H, W, win, minD, nD, flip};
-    const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
-    size_t lds = (size_t)TR * LW * GDC * 2 + (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
-    if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
-    if (lds > 64 * 1024)
-        ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_asw_geodesic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH);
-    hipLaunchKernelGGL(k_asw_geodesic, grid, dim3(256), lds, s, p, imgL, imgR, wL, wR, vol, disp);
-    ASW_HIP_TRY(hipGetLastError());
-    return ASW_OK;
+    // widest d-chunk whose cost tile still leaves two workgroups per CU (16 wide: 70 KB at win 15); big windows fall
+    // back to 8-wide chunks (win 35: 103 KB, one workgroup per CU)
+    if (geo_lds_bytes<16>(win) <= 80 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp);
+    if (geo_lds_bytes<8>(win) <= 160 * 1024) return launch_geo_t<8>(s, p, imgL, imgR, wL, wR, vol, disp);
+    return ASW_ERR_BAD_ARGUMENT;
 }

@@ -115,3 +115,21 @@ def test_bad_arguments(ctx):
     big[:, ::2] = L
     d1 = ctx.stereoMatching(big[:, ::2], R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4)
     assert np.array_equal(d1, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4))
+
+
+@pytest.mark.parametrize("win", [21, 35])
+def test_large_windows(ctx, oracle, win):
+    # config C2 uses a 35x35 window for the classic method; the other methods accept the same sizes
+    L, R, _ = make_pair(44, 100, 10, seed=win, block=16)
+    rc, dw, vw = oracle.asw_geodesic(L, R, 0, win, 0, 9, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, win, 0, 9, return_cost_volume=True)
+    assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+    rc, dw, vw = oracle.asw_guided2(L, R, 0, 1e-6, win, 0, 6, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, win, 0, 6, return_cost_volume=True)
+    assert rc == 0 and np.abs(v - vw).max() < 1e-4 and np.array_equal(d, dw)
+    rc, dw, vw = oracle.asw_blo1(L, R, 0, 0.015, win, 0, 5, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.015, win, 0, 5, return_cost_volume=True)
+    fin = np.isfinite(vw)
+    assert rc == 0 and np.allclose(v[fin], vw[fin], rtol=1e-4, atol=0) and np.array_equal(d, dw)
+    rc, ww = oracle.geodesic_dist(L[:20, :30], win, 3)
+    assert np.array_equal(ctx.getGeodesicDist(L[:20, :30], win, 3), ww)
