@@ -588,7 +588,7 @@ static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_vol
     return ASW_OK;
 }
 
-static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume)
+static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume, bool sync = true)
 {
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
     ASW_HIP_TRY(hipSetDevice(ctx->device));
@@ -605,6 +605,7 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     }
     if (rc != ASW_OK) return rc;
     ASW_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (!sync) return ASW_OK;  // pipelined callers (batch scheduler) order and wait on the stream themselves
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     float t = 0;
     ASW_HIP_TRY(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
@@ -624,6 +625,36 @@ extern "C" int asw_match_resident(asw_ctx* ctx, int slot, int disparity_type, in
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
     return run_method(ctx, f, algorithm, mp, keep_volume != 0);
+}
+
+// ---- internal hooks of the batch scheduler (batch.hip): device buffers of a slot, enqueue without waiting ----
+int asw_internal_stage_slot(asw_ctx* ctx, int slot, int rows, int cols, int channels, Frame** out)
+{
+    Frame* f = frame_slot(ctx, slot, true);
+    if (!f) return ASW_ERR_BAD_ARGUMENT;
+    const size_t bytes = (size_t)rows * cols * channels;
+    ASW_TRY(f->L.ensure(bytes));
+    ASW_TRY(f->R.ensure(bytes));
+    ASW_TRY(f->disp.ensure((size_t)rows * cols * 4));
+    f->rows = rows; f->cols = cols; f->channels = channels; f->valid = true;
+    *out = f;
+    return ASW_OK;
+}
+
+int asw_internal_enqueue_match(asw_ctx* ctx, int slot, int disparity_type, int algorithm, int win_size, int min_disparity,
+                               int num_disparity)
+{
+    Frame* f = frame_slot(ctx, slot, false);
+    if (!f || !f->valid) return ASW_ERR_NO_FRAME;
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    return run_method(ctx, f, algorithm, mp, false, false);
+}
+
+int asw_internal_check_pair(const asw_image* l, const asw_image* r, const asw_image* d)
+{
+    ASW_TRY(check_pair(l, r));
+    return check_disp_out(d, l->rows, l->cols);
 }
 
 static int match_host(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp, int algorithm,

@@ -138,3 +138,9 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
 // ---- O(1)-bilateral ASW (BLO1), k_guided.hip ----
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, const int* keys, int nk, int step, int H,
                 int W, int disp_type, int win, int numD, float* bM, float* lo, float* hi, float* vol, float* disp);
+
+// ---- hooks for the batch scheduler (batch.hip) ----
+int asw_internal_stage_slot(asw_ctx* ctx, int slot, int rows, int cols, int channels, Frame** out);
+int asw_internal_enqueue_match(asw_ctx* ctx, int slot, int disparity_type, int algorithm, int win_size, int min_disparity,
+                               int num_disparity);  // enqueues on ctx->stream, does not wait
+int asw_internal_check_pair(const asw_image* l, const asw_image* r, const asw_image* d);

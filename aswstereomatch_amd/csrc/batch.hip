@@ -1,11 +1,136 @@
-// Batch scheduler (SURVEY section 8e): frames are independent, so an N-GPU node is used batch-wise --
-// frame i goes to device device_ids[i % n_devices], one host thread + one context per device, no
-// collective and no peer traffic.  Results land in the caller's per-frame output buffers.
+// Batch scheduler (SURVEY section 8e / App. D-7): frames are independent, so an N-GPU node is used batch-wise --
+// frame i goes to device device_ids[i % n_devices], one host thread + one context per device, no collective
+// and no peer traffic.  Per device the frames are pipelined over two slots: pinned host staging, a copy stream
+// and events overlap the H2D copy of frame n+1 and the D2H copy of frame n-1 with the kernels of frame n.
+// Contexts, scratch and pinned buffers persist across calls (process lifetime).
+#include <string.h>
+
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "asw_internal.h"
+
+namespace {
+
+struct Slot {
+    void* hL = nullptr;  // pinned staging
+    void* hR = nullptr;
+    void* hD = nullptr;
+    size_t cap_img = 0, cap_disp = 0;
+    hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+    int frame = -1;  // frame whose disparity is in flight in this slot
+};
+
+int ensure_pinned(void** p, size_t* cap, size_t bytes)
+{
+    if (*p && *cap >= bytes) return ASW_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) return ASW_ERR_ALLOC;
+    *cap = bytes;
+    return ASW_OK;
+}
+
+void copy_rows(void* dst, size_t dst_step, const void* src, size_t src_step, size_t row_bytes, int rows)
+{
+    for (int y = 0; y < rows; y++) memcpy((char*)dst + (size_t)y * dst_step, (const char*)src + (size_t)y * src_step, row_bytes);
+}
+
+// Per-device state kept across batch calls: creating a context and (for the guided methods) several GB of scratch
+// costs far more than a frame, so a batch call reuses the device's context, copy stream and pinned staging.
+struct DeviceState {
+    asw_ctx* ctx = nullptr;
+    hipStream_t copy = nullptr;
+    Slot slots[2];
+    size_t cap_r[2] = {0, 0};
+    std::mutex busy;  // one batch worker per DeviceState at a time
+};
+
+std::mutex g_pool_mutex;
+std::vector<DeviceState*> g_pool;  // index = worker slot (k), so [0,0] device lists get distinct states
+std::vector<int> g_pool_device;
+
+DeviceState* acquire_state(int device, int k)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool_device[i] == device * 1024 + k) return g_pool[i];
+    DeviceState* st = new DeviceState();
+    if (asw_create(device, &st->ctx) != ASW_OK) { delete st; return nullptr; }
+    bool ok = hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking) == hipSuccess;
+    for (auto& s : st->slots)
+        ok = ok && hipEventCreate(&s.up) == hipSuccess && hipEventCreate(&s.done) == hipSuccess && hipEventCreate(&s.down) == hipSuccess;
+    if (!ok) { asw_destroy(st->ctx); delete st; return nullptr; }
+    g_pool.push_back(st);
+    g_pool_device.push_back(device * 1024 + k);
+    return st;
+}
+
+int run_device(int device, int k, int n_devices, int n_frames, const asw_image* lefts, const asw_image* rights, asw_image* disps,
+               int disparity_type, int algorithm, int win, int minD, int numD)
+{
+    DeviceState* st = acquire_state(device, k);
+    if (!st) return ASW_ERR_HIP;
+    std::lock_guard<std::mutex> lk(st->busy);
+    asw_ctx* ctx = st->ctx;
+    hipStream_t copy = st->copy;
+    Slot* slots = st->slots;
+    if (hipSetDevice(device) != hipSuccess) return ASW_ERR_HIP;
+    auto fail = [&](int code) {  // leave the device idle and the slots empty, keep the state for the next call
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(copy);
+        slots[0].frame = slots[1].frame = -1;
+        return code;
+    };
+
+    auto retire = [&](Slot& s) -> int {  // disparity of s.frame: wait for its D2H copy, hand it to the caller
+        if (s.frame < 0) return ASW_OK;
+        if (hipEventSynchronize(s.down) != hipSuccess) return ASW_ERR_HIP;
+        const asw_image& d = disps[s.frame];
+        copy_rows(d.data, d.step, s.hD, (size_t)d.cols * 4, (size_t)d.cols * 4, d.rows);
+        s.frame = -1;
+        return ASW_OK;
+    };
+
+    int rc = ASW_OK;
+    int n = 0;
+    for (int i = k; i < n_frames; i += n_devices, n++) {
+        Slot& s = slots[n & 1];
+        const asw_image &L = lefts[i], &R = rights[i];
+        rc = asw_internal_check_pair(&L, &R, &disps[i]);
+        if (rc != ASW_OK) return fail(rc);
+        rc = retire(s);  // the slot's previous frame (n-2) must be completely done before its buffers are reused
+        if (rc != ASW_OK) return fail(rc);
+        const size_t row = (size_t)L.cols * L.channels, img = row * L.rows, dsp = (size_t)L.cols * L.rows * 4;
+        if ((rc = ensure_pinned(&s.hL, &s.cap_img, img)) != ASW_OK) return fail(rc);
+        if ((rc = ensure_pinned(&s.hR, &st->cap_r[n & 1], img)) != ASW_OK) return fail(rc);
+        if ((rc = ensure_pinned(&s.hD, &s.cap_disp, dsp)) != ASW_OK) return fail(rc);
+        copy_rows(s.hL, row, L.data, L.step, row, L.rows);
+        copy_rows(s.hR, row, R.data, R.step, row, R.rows);
+        Frame* f = nullptr;
+        if ((rc = asw_internal_stage_slot(ctx, n & 1, L.rows, L.cols, L.channels, &f)) != ASW_OK) return fail(rc);
+        if (hipMemcpyAsync(f->L.p, s.hL, img, hipMemcpyHostToDevice, copy) != hipSuccess ||
+            hipMemcpyAsync(f->R.p, s.hR, img, hipMemcpyHostToDevice, copy) != hipSuccess ||
+            hipEventRecord(s.up, copy) != hipSuccess || hipStreamWaitEvent(ctx->stream, s.up, 0) != hipSuccess)
+            return fail(ASW_ERR_HIP);
+        rc = asw_internal_enqueue_match(ctx, n & 1, disparity_type, algorithm, win, minD, numD);
+        if (rc != ASW_OK) return fail(rc);
+        if (hipEventRecord(s.done, ctx->stream) != hipSuccess || hipStreamWaitEvent(copy, s.done, 0) != hipSuccess ||
+            hipMemcpyAsync(s.hD, f->disp.p, dsp, hipMemcpyDeviceToHost, copy) != hipSuccess ||
+            hipEventRecord(s.down, copy) != hipSuccess)
+            return fail(ASW_ERR_HIP);
+        s.frame = i;
+    }
+    for (int q = 0; q < 2; q++) {
+        rc = retire(slots[q]);
+        if (rc != ASW_OK) return fail(rc);
+    }
+    return ASW_OK;
+}
+
+}  // namespace
 
 extern "C" int asw_stereo_match_batch(int n_frames, const asw_image* lefts, const asw_image* rights, asw_image* disps,
                                       int disparity_type, int algorithm, int win_size, int min_disparity,
@@ -17,12 +142,8 @@ extern "C" int asw_stereo_match_batch(int n_frames, const asw_image* lefts, cons
     for (int k = 0; k < n_devices; k++) devs[k] = device_ids ? device_ids[k] : k;
     std::atomic<int> first_error(ASW_OK);
     auto worker = [&](int k) {
-        asw_ctx* ctx = nullptr;
-        int rc = asw_create(devs[k], &ctx);
-        for (int i = k; i < n_frames && rc == ASW_OK; i += n_devices)
-            rc = asw_stereo_match(ctx, &lefts[i], &rights[i], &disps[i], disparity_type, algorithm, win_size, min_disparity,
-                                  num_disparity, nullptr);
-        if (ctx) asw_destroy(ctx);
+        int rc = run_device(devs[k], k, n_devices, n_frames, lefts, rights, disps, disparity_type, algorithm, win_size,
+                            min_disparity, num_disparity);
         if (rc != ASW_OK) {
             int expected = ASW_OK;
             first_error.compare_exchange_strong(expected, rc);
