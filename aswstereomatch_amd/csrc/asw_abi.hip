@@ -315,6 +315,15 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     a.taps = ctx->bil.taps.as<int4>(); a.lut = ctx->bil.lut.as<float>(); a.ntaps = ctx->bil.ntaps;
     a.vol = keep_volume ? f->vol.as<float>() : nullptr;
     a.disp = f->disp.as<float>();
+    a.partE = nullptr; a.partD = nullptr; a.max_slices = 0;
+    if ((size_t)H * W <= (size_t)1 << 20) {  // small frames only: scratch for the grid.z split of the disparity range
+        const int max_slices = 8;
+        DevBuf& pe = ctx->buf("bil_partE");
+        DevBuf& pd = ctx->buf("bil_partD");
+        ASW_TRY(pe.ensure((size_t)max_slices * H * W * sizeof(double)));
+        ASW_TRY(pd.ensure((size_t)max_slices * H * W * sizeof(float)));
+        a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = max_slices;
+    }
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_bilateral(ctx->stream, a));
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));

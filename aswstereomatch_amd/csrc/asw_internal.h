@@ -79,6 +79,9 @@ struct BilateralLaunch {
     int flip;    // 1: mirrored problem (DISPARITY_RIGHT), taps must come from the mirrored table
     float* vol;  // optional [nD][H][W]
     float* disp; // [H][W]
+    double* partE;  // optional scratch [max_slices][H][W]: per-slice winners when the d range is split over grid.z
+    float* partD;
+    int max_slices;
 };
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 int bilateral_lds_row_stride(int win);  // LW of the kernel's sample tile (taps[].x is expressed in it)

@@ -27,6 +27,8 @@
 // This kernel is f64-VALU-bound, not HBM-bound ("Rooflines").
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "asw_internal.h"
 
 namespace {
@@ -38,6 +40,7 @@ constexpr int DCMAX = 16;  // widest d-chunk
 struct BilParams {
     int H, W, h, minD, nD, ntaps;
     int flip;  // 1: the problem is mirrored in x (DISPARITY_RIGHT = DISPARITY_LEFT on mirrored, swapped images)
+    int cand_per_z;  // candidates per grid.z slice (multiple of 16); small images split the d range over grid.z
 };
 
 constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -216,7 +219,8 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
 template <int HH, int G, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_asw_bilateral(
     BilParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ taps,
-    const float* __restrict__ lut, float* __restrict__ vol, float* __restrict__ disp)
+    const float* __restrict__ lut, float* __restrict__ vol, float* __restrict__ disp, double* __restrict__ partE,
+    float* __restrict__ partD)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const Layout lay(HH > 0 ? HH : p.h, G);
@@ -234,15 +238,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
     double bestE = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
     float bestD = 0.0f;
-    int c0 = 0;
-    for (; c0 + 16 <= p.nD; c0 += 16) process_chunk<16, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD);
-    if (p.nD - c0 >= 8) { process_chunk<8, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 8; }
-    if (p.nD - c0 >= 4) { process_chunk<4, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 4; }
-    if (p.nD - c0 >= 2) { process_chunk<2, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 2; }
-    if (p.nD - c0 >= 1) { process_chunk<1, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 1; }
+    // this workgroup's candidate range [c0, cEnd): the whole range, or one grid.z slice of it for small images
+    int c0 = blockIdx.z * p.cand_per_z;
+    const int cEnd = min(p.nD, c0 + p.cand_per_z);
+    for (; c0 + 16 <= cEnd; c0 += 16) process_chunk<16, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD);
+    if (cEnd - c0 >= 8) { process_chunk<8, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 8; }
+    if (cEnd - c0 >= 4) { process_chunk<4, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 4; }
+    if (cEnd - c0 >= 2) { process_chunk<2, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 2; }
+    if (cEnd - c0 >= 1) { process_chunk<1, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 1; }
 
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
-    if (x < W && y < H) disp[(size_t)y * W + (p.flip ? W - 1 - x : x)] = bestD;
+    if (x < W && y < H) {
+        const size_t o = (size_t)y * W + (p.flip ? W - 1 - x : x);
+        if (gridDim.z == 1) {
+            disp[o] = bestD;
+        } else {  // per-slice winners; k_merge_slices picks the first strict minimum in ascending d
+            partE[(size_t)blockIdx.z * H * W + o] = bestE;
+            partD[(size_t)blockIdx.z * H * W + o] = bestD;
+        }
+    }
+}
+
+// winners of the grid.z slices -> WTA of the whole range (M.cpp:1145-1150: strict '<' while d ascends)
+__global__ __launch_bounds__(256) void k_merge_slices(const double* __restrict__ partE, const float* __restrict__ partD, int nz,
+                                                      size_t plane, float* __restrict__ disp)
+{
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= plane) return;
+    double best = 1.7976931348623157e308;
+    float bd = 0.0f;
+    for (int z = 0; z < nz; z++) {
+        const double e = partE[(size_t)z * plane + o];
+        if (e < best) { best = e; bd = partD[(size_t)z * plane + o]; }
+    }
+    disp[o] = bd;
 }
 
 template <int HH, int G, int WPE = 2>
@@ -257,7 +286,20 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total));
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH);
     if (a.ntaps % G != 0) return ASW_ERR_BAD_ARGUMENT;  // cannot happen for odd windows
-    hipLaunchKernelGGL(kern, grid, dim3(256), lay.total, s, p, a.gL, a.gR, a.taps, a.lut, a.vol, a.disp);
+    // Small images do not fill 256 CUs with tiles alone (C2: 450x375 -> 752 tiles): split the candidate range over
+    // grid.z in multiples of 16 until there are ~2048 workgroups, and merge the per-slice winners afterwards.
+    const int tiles = grid.x * grid.y, chunks16 = (a.nD + 15) / 16;
+    int nz = 1;
+    if (a.partE && a.partD && tiles < 2048) nz = std::min(chunks16, std::min(a.max_slices, (2048 + tiles - 1) / tiles));
+    const int chunks_per_z = (chunks16 + nz - 1) / nz;
+    nz = (chunks16 + chunks_per_z - 1) / chunks_per_z;
+    p.cand_per_z = chunks_per_z * 16;
+    grid.z = nz;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lay.total, s, p, a.gL, a.gR, a.taps, a.lut, a.vol, a.disp, a.partE, a.partD);
+    if (nz > 1) {
+        const size_t plane = (size_t)a.H * a.W;
+        hipLaunchKernelGGL(k_merge_slices, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, a.partE, a.partD, nz, plane, a.disp);
+    }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
