@@ -62,6 +62,12 @@ struct Layout {
     }
 };
 
+// 32-bit byte offset from a uniform base: global_load with an SGPR base, no 64-bit address arithmetic per lane
+__device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned idx)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lut) + (idx << 2));
+}
+
 template <int DC>
 __device__ __forceinline__ void load_cost(const uint8_t* cell, uint32_t (&cw)[(DC + 3) / 4])
 {
@@ -162,24 +168,38 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
 
     for (int g0 = 0; g0 < p.ntaps; g0 += G) {
         __syncthreads();  // previous group's weights consumed (first pass: cost tile complete)
+        // All LUT gathers of a group are issued back to back (index pass, gather pass, store pass): one memory round
+        // trip per group instead of one per weight.
+        {
+            unsigned ia[G], il[G];
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            const int4 tp = taps[g0 + t];  // uniform: scalar loads
-            // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
-            {
+            for (int t = 0; t < G; t++) {
+                const int4 tp = taps[g0 + t];  // uniform: scalar loads
+                // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
                 int nc = min(max(colA + tp.y, colLo), colHi);
-                int nb = rowA[tp.z * RWp + nc];
-                dstA[t * (TH * SWR)] = lut[__builtin_amdgcn_sad_u16(nb, ctrA, tp.w)];
+                ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
+                // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
+                il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
             }
-            if (DC > 1 && ty == 0) {
-                if (tx < NEXTRA) {
-                    int nc = min(max(colB + tp.y, colLo), colHi);
-                    int nb = rowB[tp.z * RWp + nc];
-                    dstB[t * (TH * SWR)] = lut[__builtin_amdgcn_sad_u16(nb, ctrB, tp.w)];
-                }
+            float wa[G], wl[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) { wa[t] = lut_at(lut, ia[t]); wl[t] = lut_at(lut, il[t]); }
+#pragma unroll
+            for (int t = 0; t < G; t++) { dstA[t * (TH * SWR)] = wa[t]; sWL[t * (TH * TW) + tid] = wl[t]; }
+        }
+        if (DC > 1 && tid < NEXTRA) {  // wave 0: the DC-1 extra right-weight columns of all four rows
+            unsigned ib[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                const int4 tp = taps[g0 + t];
+                int nc = min(max(colB + tp.y, colLo), colHi);
+                ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + nc], ctrB, tp.w);
             }
-            // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
-            sWL[t * (TH * TW) + tid] = lut[__builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w)];
+            float wb[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) wb[t] = lut_at(lut, ib[t]);
+#pragma unroll
+            for (int t = 0; t < G; t++) dstB[t * (TH * SWR)] = wb[t];
         }
         __syncthreads();
         // rolled on purpose: one tap's operands (1 + 4 + DC registers) live at a time keeps the kernel at
