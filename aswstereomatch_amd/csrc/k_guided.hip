@@ -42,7 +42,7 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 //   * ND slices per wavefront: operands that do not depend on the slice (guide pixel, guide statistics) are
 //     fetched once -- the ND fetches are issued back to back with identical addresses and merge (CSE).
 template <int NP, int CPL, int ND, int WPE, class Src, class Dst>
-__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices)
+__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices, int ngx, int nby)
 {
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -50,16 +50,26 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     double* hs = reinterpret_cast<double*>(smem) + (size_t)wv * ND * NP * (SW + 2);  // [ND][NP][SW+2] per wavefront
     const int hl = k / 2;  // OpenCV anchor = k/2 (also for even k)
     const int XO = SW - (k - 1);
-    const int xw = blockIdx.x * 4 + wv;  // wavefront's strip index
-    if (xw >= nxw) return;               // whole wavefront exits
+    // Workgroup -> (region, slice group), XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so the ones with
+    // equal blockIdx.x % 8 share an L2.  Each XCD takes every 8th region (a band of 4 strips) and runs through ALL
+    // slices of it before the next region, so whatever does not depend on the slice (guide pixels, guide statistics)
+    // and the halo rows/columns are fetched from HBM once per region and hit in that XCD's L2 afterwards.
+    const int nzg = (nslices + ND - 1) / ND;
+    const int wj = blockIdx.x >> 3;
+    const int zg = wj % nzg;
+    const int reg = (wj / nzg) * 8 + (blockIdx.x & 7);
+    if (reg >= ngx * nby) return;
+    const int gx = reg % ngx, by = reg / ngx;
+    const int xw = gx * 4 + wv;  // wavefront's strip index
+    if (xw >= nxw) return;       // whole wavefront exits
     const int xo0 = xw * XO;
     const int c0 = CPL * lane;           // first strip column of this lane
     int kz[ND];
     bool kvalid[ND];
 #pragma unroll
     for (int n = 0; n < ND; n++) {
-        kvalid[n] = (int)blockIdx.z * ND + n < nslices;
-        kz[n] = min((int)blockIdx.z * ND + n, nslices - 1);
+        kvalid[n] = zg * ND + n < nslices;
+        kz[n] = min(zg * ND + n, nslices - 1);
     }
     int xin[CPL];
     bool out_col[CPL];
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         out_col[c] = (c0 + c < XO) && (xo0 + c0 + c < W);
     }
     const bool any_out = out_col[0];  // columns are adjacent: column 1 is an output only if column 0 is
-    const int y0 = blockIdx.y * band, y1 = min(H, y0 + band);
+    const int y0 = by * band, y1 = min(H, y0 + band);
     const double scale = 1.0 / ((double)k * (double)k);
     double vs[CPL][ND][NP];
 #pragma unroll
@@ -392,8 +402,10 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
     auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
-    dim3 grid((nxw + 3) / 4, (H + band - 1) / band, (n + ND - 1) / ND);
-    hipLaunchKernelGGL(kern, grid, dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n);
+    const int ngx = (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = (n + ND - 1) / ND;
+    const long long nwg = (long long)((ngx * nby + 7) / 8) * 8 * nzg;  // regions rounded up to a multiple of the 8 XCDs
+    if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
