@@ -3,6 +3,8 @@
 //   REFLECT padding of the planes (M.cpp:651-668), per-slice min/max (normalize NORM_MINMAX, M.cpp:2774-2775).
 // All arithmetic follows the MatExpr evaluation order of M.cpp:455-484 operation by operation; the
 // library is compiled with -ffp-contract=off so no a*b+c is fused behind our back.
+#include <math.h>
+
 #include "asw_internal.h"
 
 namespace {
@@ -41,22 +43,26 @@ __global__ __launch_bounds__(256) void k_scharr_x(const uint8_t* __restrict__ im
     }
 }
 
-__device__ __forceinline__ float similarity_pixel(int c0, int c1, int c2, float g0, float g1, float g2, float rr, float rg,
-                                                  float thresCf, double thresC, double thresG, float thresGf)
+// One pixel of the TAD C+G cost.  c01 = c0+c1, c2: absolute colour differences; g01 = g0+g1, g2: absolute gradient
+// differences (exact integers, so the float sums/differences of the reference are exact too).
+// tCi = floor(thresC): for an integer colour, (double)colour > thresC  <=>  colour > floor(thresC);
+// tGdn = largest float <= thresG: for a float g, (double)g > thresG  <=>  g > tGdn.
+__device__ __forceinline__ float similarity_pixel(int c01, int c2, int g01i, int g2i, float rr, float rg, float thresCf,
+                                                  int tCi, float tGdn, float thresGf)
 {
     // colour term (u8): (c0+c1+c2)/3 -> round((min(255,c0+c1)+c2)/3); >thresC ? min(255, v+thresC) : 0  (M.cpp:459-465)
-    int t = min(255, c0 + c1);
+    int t = min(255, c01);
     int color = (t + c2 + 1) / 3;
-    int maskC = ((double)color > thresC) ? 1 : 0;
+    int maskC = (color > tCi) ? 1 : 0;
     float tf = (float)(color * maskC) * 1.0f + 255.0f * (float)maskC * thresCf;  // addWeighted(m1,1,mask,thresC/255)
     int cc_i = __float2int_rn(tf);                                                 // cvRound: to nearest even
     cc_i = min(255, max(0, cc_i));
     float cc = (float)cc_i;
     // gradient term (f32): (g0+g1+g2)/3 = addWeighted(g0+g1, 1/3, g2, 1/3)   (M.cpp:473)
     const float third = (float)(1.0 / 3.0);
-    float g01 = g0 + g1;
+    float g01 = (float)g01i, g2 = (float)g2i;
     float g = g01 * third + g2 * third;
-    int maskG = ((double)g > thresG) ? 1 : 0;           // compare(>thresG)/255
+    int maskG = (g > tGdn) ? 1 : 0;                     // compare(>thresG)/255
     float bit = (float)maskG, bit_not = (float)(255 - maskG);  // bitwise_not of a 0/1 mask: 255/254 (App. B-6)
     float gm = g * bit;
     float cg = bit_not * thresGf + gm;                  // scaleAdd(bit_not, thresG, gm)     (M.cpp:482)
@@ -99,52 +105,106 @@ __device__ __forceinline__ void block_minmax_commit(uint32_t lo, uint32_t hi, ui
     }
 }
 
+// min / max over the 16 lanes of every DPP row, result in all lanes of the row
+template <bool MAX>
+__device__ __forceinline__ uint32_t row_reduce_u32(uint32_t v)
+{
+#define ASW_STEP(ctrl)                                                                                         \
+    {                                                                                                          \
+        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false);             \
+        v = MAX ? max(v, o) : min(v, o);                                                                       \
+    }
+    ASW_STEP(0xB1)   // quad_perm [1,0,3,2]
+    ASW_STEP(0x4E)   // quad_perm [2,3,0,1]
+    ASW_STEP(0x141)  // row_half_mirror
+    ASW_STEP(0x140)  // row_mirror
+#undef ASW_STEP
+    return v;
+}
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v)
+{
+    v = row_reduce_u32<MAX>(v);
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+             d = __builtin_amdgcn_readlane(v, 48);
+    return MAX ? max(max(a, b), max(c, d)) : min(min(a, b), min(c, d));
+}
+
 // computeSimilarity, DISPARITY_LEFT + 3 channels (the only branch that can execute, App. B-7).
-// grid: (ceil(W/256), ceil(H/ROWS), numD); cost plane k <-> offset minD+k.
-constexpr int SIM_ROWS = 8;
+// A workgroup owns 256 columns x SIM_ROWS rows and runs through a chunk of up to SIM_DCH candidates itself: the left
+// pixel and gradient stay in registers, the right-image row segment every candidate shifts over (256 + chunk - 1
+// columns, colours packed BGRX, gradients as 3 x i16) is staged in LDS once, so the images are read from HBM ~1.5x
+// instead of once per candidate.  grid: (ceil(W/256), ceil(H/SIM_ROWS), ceil(numD/SIM_DCH)); plane k <-> offset minD+k.
+constexpr int SIM_ROWS = 4;
+constexpr int SIM_DCH = 512;
 __global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
                                                     const short* __restrict__ gL, const short* __restrict__ gR, int H, int W,
-                                                    int minD, int numD, float rr, float rg, float thresCf, double thresC,
-                                                    double thresG, float thresGf, float* __restrict__ cost,
-                                                    uint32_t* __restrict__ parts /* optional [numD][blocks][2] min/max keys */)
+                                                    int minD, int numD, float rr, float rg, float thresCf, int tCi, float tGdn,
+                                                    float thresGf, float* __restrict__ cost,
+                                                    uint32_t* __restrict__ parts /* optional [numD][waves][2] min/max keys */)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = blockIdx.z, off = minD + k, max_off = minD + numD - 1, Wb = W + max_off;
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    if (x < W) {
-    const int cb = max_off - off + x;              // column in the padded right image (M.cpp:455)
-    const int xr = reflect_idx(cb - max_off, W);   // = reflect(x - off)
-    const int y0 = blockIdx.y * SIM_ROWS, y1 = min(H, y0 + SIM_ROWS);
-    for (int y = y0; y < y1; y++) {
-        const uint8_t* a = L + ((size_t)y * W + x) * 3;
-        const uint8_t* b = R + ((size_t)y * W + xr) * 3;
-        const short* ga = gL + ((size_t)y * W + x) * 3;
-        const short* gb = gR + ((size_t)y * Wb + cb) * 3;
-        int c0 = abs((int)a[0] - (int)b[0]), c1 = abs((int)a[1] - (int)b[1]), c2 = abs((int)a[2] - (int)b[2]);
-        float g0 = fabsf((float)ga[0] - (float)gb[0]), g1 = fabsf((float)ga[1] - (float)gb[1]),
-              g2 = fabsf((float)ga[2] - (float)gb[2]);
-        float v = similarity_pixel(c0, c1, c2, g0, g1, g2, rr, rg, thresCf, thresC, thresG, thresGf);
-        cost[((size_t)k * H + y) * W + x] = v;
-        uint32_t o = f2ord(v);
-        lo = min(lo, o);
-        hi = max(hi, o);
+    extern __shared__ __align__(16) uint32_t sim_smem[];
+    const int tid = threadIdx.x, x0 = blockIdx.x * 256, y0 = blockIdx.y * SIM_ROWS;
+    const int kb = blockIdx.z * SIM_DCH, ke = min(numD, kb + SIM_DCH);
+    const int max_off = minD + numD - 1, Wb = W + max_off;
+    const int WL = 256 + (ke - kb) - 1, WLp = (WL + 1) & ~1;
+    const int u0 = x0 - (minD + ke - 1);  // u = x - offset: leftmost shifted column this chunk touches
+    uint32_t* sC = sim_smem;                                            // [SIM_ROWS][WLp] B | G<<8 | R<<16
+    uint2* sG = reinterpret_cast<uint2*>(sim_smem + SIM_ROWS * WLp);     // [SIM_ROWS][WLp] {g0 | g1<<16, g2}
+    for (int i = tid; i < SIM_ROWS * WL; i += 256) {
+        const int r = i / WL, j = i - r * WL;
+        const int y = min(y0 + r, H - 1), u = u0 + j;
+        const uint8_t* b = R + ((size_t)y * W + reflect_idx(u, W)) * 3;          // M.cpp:455: REFLECT-padded right image
+        const short* gb = gR + ((size_t)y * Wb + min(max(u + max_off, 0), Wb - 1)) * 3;
+        sC[r * WLp + j] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+        sG[r * WLp + j] = make_uint2((uint32_t)(uint16_t)gb[0] | ((uint32_t)(uint16_t)gb[1] << 16), (uint32_t)(int)gb[2]);
     }
-    }
-    // normalize(NORM_MINMAX) of this slice needs its global min/max (M.cpp:2775).  Per-block partials, reduced by
-    // k_scales_from_parts: same-address atomics from 10^5 workgroups serialise (measured: +3.3 ms per frame).
-    if (parts) {
-        __shared__ uint32_t s_lo[4], s_hi[4];
+    const int x = x0 + tid, xc = min(x, W - 1);
+    const int nrows = min(SIM_ROWS, H - y0);
+    uint32_t a01[SIM_ROWS], a2[SIM_ROWS];
+    int ga0[SIM_ROWS], ga1[SIM_ROWS], ga2[SIM_ROWS];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    for (int r = 0; r < SIM_ROWS; r++) {
+        const int y = min(y0 + r, H - 1);
+        const uint8_t* a = L + ((size_t)y * W + xc) * 3;
+        const short* ga = gL + ((size_t)y * W + xc) * 3;
+        a01[r] = (uint32_t)a[0] | ((uint32_t)a[1] << 8);
+        a2[r] = (uint32_t)a[2];
+        ga0[r] = ga[0]; ga1[r] = ga[1]; ga2[r] = ga[2];
+    }
+    __syncthreads();
+    const int nb = gridDim.x * gridDim.y * 4, bw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6);
+    for (int k = kb; k < ke; k++) {
+        const int j = tid + (ke - 1 - k);  // (x - (minD + k)) - u0
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int r = 0; r < SIM_ROWS; r++) {
+            if (r < nrows) {
+                const uint32_t b = sC[r * WLp + j];
+                const uint2 gb = sG[r * WLp + j];
+                // |a0-b0| + |a1-b1| and |a2-b2| with the byte SAD unit
+                const int c01 = (int)__builtin_amdgcn_sad_u8(a01[r], b & 0xffffu, 0u);
+                const int c2 = (int)__builtin_amdgcn_sad_u8(a2[r], b >> 16, 0u);
+                const int g01 = abs(ga0[r] - (int)(short)(gb.x & 0xffffu)) + abs(ga1[r] - ((int)gb.x >> 16));
+                const int g2 = abs(ga2[r] - (int)gb.y);
+                const float v = similarity_pixel(c01, c2, g01, g2, rr, rg, thresCf, tCi, tGdn, thresGf);
+                if (x < W) {
+                    cost[((size_t)k * H + (y0 + r)) * W + x] = v;
+                    const uint32_t o = f2ord(v);
+                    lo = min(lo, o);
+                    hi = max(hi, o);
+                }
+            }
         }
-        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
-            parts[((size_t)k * nb + b) * 2] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-            parts[((size_t)k * nb + b) * 2 + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        // normalize(NORM_MINMAX) of this slice needs its global min/max (M.cpp:2775).  Per-wavefront partials, reduced
+        // by k_scales_from_parts: same-address atomics from 10^5 workgroups serialise (measured: +3.3 ms per frame).
+        if (parts) {
+            lo = wave_reduce_u32<false>(lo);
+            hi = wave_reduce_u32<true>(hi);
+            if ((tid & 63) == 0) {
+                parts[((size_t)k * nb + bw) * 2] = lo;
+                parts[((size_t)k * nb + bw) * 2 + 1] = hi;
+            }
         }
     }
 }
@@ -283,21 +343,28 @@ int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const s
                       int minD, int numD, double regularity, double thresC, double thresG, float* cost, uint32_t* ord_scratch,
                       float2* scales)
 {
-
-    dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, numD);
+    const int nz = (numD + SIM_DCH - 1) / SIM_DCH, chunk = numD < SIM_DCH ? numD : SIM_DCH;
+    dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, nz);
+    const int WLp = (256 + chunk - 1 + 1) & ~1;
+    const size_t lds = (size_t)SIM_ROWS * WLp * 12;
     float rr = (float)(1.0 - regularity), rg = (float)regularity;  // regularityR, M.cpp:435
     float thresCf = (float)(thresC * (1.0 / 255.0));
-    hipLaunchKernelGGL(k_similarity, grid, dim3(256), 0, s, L, R, gL, gR, H, W, minD, numD, rr, rg, thresCf, thresC, thresG,
+    // integer / float forms of the two double comparisons (see similarity_pixel)
+    double fc = floor(thresC);
+    int tCi = fc < -1.0 ? -1 : (fc > 1e6 ? 1000000 : (int)fc);
+    float tGdn = (float)thresG;
+    if ((double)tGdn > thresG) tGdn = nextafterf(tGdn, -INFINITY);
+    hipLaunchKernelGGL(k_similarity, grid, dim3(256), lds, s, L, R, gL, gR, H, W, minD, numD, rr, rg, thresCf, tCi, tGdn,
                        (float)thresG, cost, ord_scratch);
     if (ord_scratch && scales)
-        hipLaunchKernelGGL(k_scales_from_parts, dim3(numD), dim3(256), 0, s, ord_scratch, (int)(grid.x * grid.y), scales);
+        hipLaunchKernelGGL(k_scales_from_parts, dim3(numD), dim3(256), 0, s, ord_scratch, (int)(grid.x * grid.y * 4), scales);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
 
 size_t similarity_parts_words(int H, int W, int numD)
 {
-    return (size_t)2 * numD * ((W + 255) / 256) * ((H + SIM_ROWS - 1) / SIM_ROWS);
+    return (size_t)2 * numD * ((W + 255) / 256) * ((H + SIM_ROWS - 1) / SIM_ROWS) * 4;
 }
 
 int launch_pad_reflect(hipStream_t s, const float* src, int n, int H, int W, int h, float* dst)
