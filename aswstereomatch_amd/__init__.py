@@ -25,7 +25,7 @@ __all__ = [
     "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
     "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
     "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
-    "stereoMatchingBatch", "computeAdaptiveWeight_BLO1",
+    "stereoMatchingBatch", "computeAdaptiveWeight_BLO1", "computeAdaptiveWeight_direct8",
     "AswError",
 ]
 
@@ -117,7 +117,8 @@ class Context:
 
     @staticmethod
     def _candidates(algorithm, numDisparity):
-        inclusive = algorithm in (StereoMatchingAlgorithms.ADAPTIVE_WEIGHT, StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_GEODESIC)
+        inclusive = algorithm in (StereoMatchingAlgorithms.ADAPTIVE_WEIGHT, StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_8DIRECT,
+                                  StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_GEODESIC)
         return numDisparity + (1 if inclusive else 0)
 
     # ---- whole-method entry point (M.h:91-92) ----
@@ -158,6 +159,12 @@ class Context:
         return self._aggregate(self._lib.asw_aggregate_bilateral, "asw_aggregate_bilateral", numDisparity + 1, leftImg,
                                rightImg, (float(gamma_c), float(gamma_g), int(dispType), winSize, minDisparity, numDisparity),
                                return_cost_volume)
+
+    def computeAdaptiveWeight_direct8(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=186,
+                                      numDisparity=144, return_cost_volume=False):
+        """M.h:135-136, M.cpp:1167-1319 (DISPARITY_LEFT only: the reference's RIGHT branch is undefined behaviour)."""
+        return self._aggregate(self._lib.asw_aggregate_direct8, "asw_aggregate_direct8", numDisparity + 1, leftImg,
+                               rightImg, (int(dispType), winSize, minDisparity, numDisparity), return_cost_volume)
 
     def computeAdaptiveWeight_geodesic(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=186,
                                        numDisparity=144, return_cost_volume=False):
@@ -343,6 +350,7 @@ computeTAD = _bind("computeTAD")
 computeSimilarity = _bind("computeSimilarity")
 getCostSAD = _bind("getCostSAD")
 computeAdaptiveWeight = _bind("computeAdaptiveWeight")
+computeAdaptiveWeight_direct8 = _bind("computeAdaptiveWeight_direct8")
 computeAdaptiveWeight_geodesic = _bind("computeAdaptiveWeight_geodesic")
 getGeodesicDist = _bind("getGeodesicDist")
 getGuidedFilter = _bind("getGuidedFilter")

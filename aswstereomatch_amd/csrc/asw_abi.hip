@@ -223,24 +223,38 @@ extern "C" int asw_download_volume(asw_ctx* ctx, int slot, float* out, size_t n_
 // ------------------------------------------------------------------------------------------
 // mirror = 1: table for the x-mirrored problem (DISPARITY_RIGHT runs as DISPARITY_LEFT on mirrored, swapped images:
 // M.cpp:1134-1138 is M.cpp:1104-1108 under x -> W-1-x), i.e. every x direction negated, tap ORDER unchanged.
-static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double gamma_g, int mirror)
+// Tap table + weight LUT of the bilateral kernel.  kind 0: computeAdaptiveWeight (M.cpp:1041-1102);
+// kind 1: computeAdaptiveWeight_direct8 (M.cpp:1195-1221, 1238-1259).
+static int ensure_bilateral_tables(asw_ctx* ctx, int kind, int win, double gamma_c, double gamma_g, int mirror)
 {
     BilateralTables& t = ctx->bil;
-    if (t.win == win && t.gamma_c == gamma_c && t.gamma_g == gamma_g && t.mirror == mirror && t.taps.p) return ASW_OK;
-    const int ks = win, h = ks / 2, nt = ks * ks - 1;
-    std::vector<int> dxw(nt), dyw(nt), dxs(nt), dys(nt);
-    int n = 0;
-    for (int j = -h; j < h + 1; j++)          // build order of the weight maps, M.cpp:1044-1053
-        for (int i = -h; i < h + 1; i++) {
-            if (i == 0 && j == 0) continue;
-            dxw[n] = i; dyw[n] = j; n++;
+    if (t.kind == kind && t.win == win && t.gamma_c == gamma_c && t.gamma_g == gamma_g && t.mirror == mirror && t.taps.p)
+        return ASW_OK;
+    const int ks = win, h = ks / 2;
+    std::vector<int> dxw, dyw, dxs, dys;  // weight direction (build order) / sample offset (consume order)
+    if (kind == 0) {
+        const int nt = ks * ks - 1;
+        dxs.resize(nt); dys.resize(nt);
+        for (int j = -h; j < h + 1; j++)          // build order of the weight maps, M.cpp:1044-1053
+            for (int i = -h; i < h + 1; i++) {
+                if (i == 0 && j == 0) continue;
+                dxw.push_back(i); dyw.push_back(j);
+            }
+        for (int i = 0; i < nt; i++) {            // consume order of the samples, M.cpp:1088-1102
+            int kx, ky;
+            if (i > ks * ks / 2) { kx = (i + 1) / ks; ky = (i + 1) % ks; }
+            else { kx = i / ks; ky = i % ks; }
+            dxs[i] = -h + kx; dys[i] = -h + ky;
         }
-    for (int i = 0; i < nt; i++) {            // consume order of the samples, M.cpp:1088-1102
-        int kx, ky;
-        if (i > ks * ks / 2) { kx = (i + 1) / ks; ky = (i + 1) % ks; }
-        else { kx = i / ks; ky = i % ks; }
-        dxs[i] = -h + kx; dys[i] = -h + ky;
+    } else {
+        for (int j = -h; j < h + 1; j++)          // M.cpp:1195-1201 == 1238-1245: same order, same test
+            for (int i = -h; i < h + 1; i++) {
+                if (i == 0 && j == 0) continue;
+                if (i == j || i == 0 || j == 0 || (i + j) == ks - 1) { dxw.push_back(i); dyw.push_back(j); }
+            }
+        dxs = dxw; dys = dyw;                     // the sample is the neighbour the weight was built for
     }
+    const int nt = (int)dxw.size();
     // distance classes: distinct values of i*i + j*j
     std::vector<int> cls_of_r2(2 * h * h + 1, -1);
     std::vector<int> r2s;
@@ -248,32 +262,35 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int win, double gamma_c, double
         int r2 = dxw[i] * dxw[i] + dyw[i] * dyw[i];
         if (cls_of_r2[r2] < 0) { cls_of_r2[r2] = (int)r2s.size(); r2s.push_back(r2); }
     }
-    std::vector<float> lut(r2s.size() * 256);
-    const double k = 3;  // M.cpp:1024
+    // The kernel consumes taps in groups of 4: pad with taps of an all-zero weight class (0*w*c adds +0.0 to both sums).
+    const int nt_pad = (nt + 3) / 4 * 4, zero_cls = (int)r2s.size();
+    std::vector<float> lut((r2s.size() + 1) * 256, 0.0f);
+    const double k = 3;  // M.cpp:1024, 1175
     for (size_t c = 0; c < r2s.size(); c++) {
-        double delta_g = sqrt((double)r2s[c]);  // M.cpp:1054
+        double delta_g = sqrt((double)r2s[c]);  // M.cpp:1054, 1205
         for (int dc = 0; dc < 256; dc++) {
             double delta_c = (double)dc;
-            lut[c * 256 + dc] = (float)(k * exp(-(delta_c / gamma_c + delta_g / gamma_g)));  // M.cpp:1065
+            lut[c * 256 + dc] = (float)(k * exp(-(delta_c / gamma_c + delta_g / gamma_g)));  // M.cpp:1065, 1214
         }
     }
-    std::vector<int4> taps(nt);
+    std::vector<int4> taps(nt_pad);
     const int LW = bilateral_lds_row_stride(win);  // row stride of the kernel's LDS sample tile
     for (int i = 0; i < nt; i++) {
         const int sx = mirror ? -1 : 1;
-        taps[i].x = dys[i] * LW + sx * dxs[i];  // sample cell, consume order (transposed, App. B-2)
+        taps[i].x = dys[i] * LW + sx * dxs[i];  // sample cell, consume order (classic: transposed, App. B-2)
         taps[i].y = sx * dxw[i];                // weight direction, build order
         taps[i].z = dyw[i];
         taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256;
     }
+    for (int i = nt; i < nt_pad; i++) taps[i] = make_int4(0, 0, 0, zero_cls * 256);
     ASW_TRY(t.taps.ensure(taps.size() * sizeof(int4)));
     ASW_TRY(t.lut.ensure(lut.size() * sizeof(float)));
-    if (!taps.empty()) {  // win = 1 has no taps at all (every E is 0/0)
+    if (!taps.empty())  // win = 1 has no taps at all (every E is 0/0)
         ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    }
+    ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
-    t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.mirror = mirror; t.ntaps = nt; t.ncls = (int)r2s.size();
+    t.kind = kind; t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.mirror = mirror; t.ntaps = nt_pad;
+    t.ncls = (int)r2s.size() + 1;
     return ASW_OK;
 }
 
@@ -285,16 +302,23 @@ struct MatchParams {
     double blo_rate_r = 0.015;          // M.cpp:70
 };
 
-static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+// computeAdaptiveWeight (direct8 = false) and computeAdaptiveWeight_direct8 (direct8 = true: sparse support, its own
+// gamma_g, DISPARITY_LEFT only -- the RIGHT branch of the reference indexes its weight vectors with a negative tap
+// coordinate, M.cpp:1291-1295)
+static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume, bool direct8 = false)
 {
     if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // build decision: the reference has no guard
     if (mp.win < 1) return ASW_ERR_BAD_ARGUMENT;
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;  // cvtColor(BGR2GRAY) asserts scn==3/4
     if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    if (direct8 && mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
     const int flip = mp.disparity_type == ASW_DISPARITY_RIGHT ? 1 : 0;
     if (mp.win > 127) return ASW_ERR_BAD_ARGUMENT;
     const int H = f->rows, W = f->cols, nD = mp.numD + 1;  // inclusive range, M.cpp:1021,1074
-    ASW_TRY(ensure_bilateral_tables(ctx, mp.win, mp.gamma_c, mp.gamma_g, flip));
+    if (direct8)
+        ASW_TRY(ensure_bilateral_tables(ctx, 1, mp.win, 30.0, (double)(mp.win * 2 / 3), 0));  // M.cpp:1175: integer division
+    else
+        ASW_TRY(ensure_bilateral_tables(ctx, 0, mp.win, mp.gamma_c, mp.gamma_g, flip));
     DevBuf& gl = ctx->buf("grayL");
     DevBuf& gr = ctx->buf("grayR");
     ASW_TRY(gl.ensure((size_t)H * W));
@@ -605,6 +629,7 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     int rc;
     switch (algorithm) {  // M.cpp:49-87
     case ASW_ALG_ADAPTIVE_WEIGHT: rc = run_bilateral(ctx, f, mp, keep_volume); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT: rc = run_bilateral(ctx, f, mp, keep_volume, true); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC: rc = run_geodesic(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_BLO1: rc = run_blo1(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, false); break;
@@ -698,6 +723,15 @@ extern "C" int asw_aggregate_bilateral(asw_ctx* ctx, const asw_image* left, cons
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
     mp.gamma_c = gamma_c; mp.gamma_g = gamma_g;
     return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT, mp, cost_volume_out);
+}
+
+extern "C" int asw_aggregate_direct8(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                     int disparity_type, int win_size, int min_disparity, int num_disparity,
+                                     float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT, mp, cost_volume_out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ struct Frame {
     bool valid = false;
 };
 
-struct BilateralTables {  // cached per (win, gamma_c, gamma_g, mirror)
+struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
+    int kind = -1;  // 0: classic (all win*win-1 taps, transposed consume order), 1: direct8 (row + column + diagonal)
     int win = 0;
     int mirror = -1;
     double gamma_c = 0, gamma_g = 0;

@@ -196,6 +196,15 @@ inline AswMat computeAdaptiveWeight(AswMat leftImg, AswMat rightImg, double gamm
     }, "computeAdaptiveWeight");
 }
 
+// M.h:135-136 (DISPARITY_RIGHT: undefined behaviour in the reference, M.cpp:1291-1295 -> empty Mat here)
+inline AswMat computeAdaptiveWeight_direct8(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, int winSize = 7,
+                                            int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_direct8(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_direct8");
+}
+
 // M.h:142-143
 inline AswMat computeAdaptiveWeight_geodesic(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, int winSize = 7,
                                              int minDisparity = 186, int numDisparity = 144)

@@ -30,7 +30,7 @@ typedef enum asw_status {
     ASW_OK = 0,
     ASW_ERR_SIZE_MISMATCH = 1,      /* M.cpp:217-220, 313-316, 430-433: silent return          */
     ASW_ERR_EVEN_WINDOW = 2,        /* M.cpp:654-657, 1440-1443, 2458-2462, 3238-3241: Mat()  */
-    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,3,5,9,11)        */
+    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,5,9,11)          */
     ASW_ERR_UNSUPPORTED_LAYOUT = 4, /* where the reference throws cv::Exception (SURVEY B-7)  */
     ASW_ERR_HIP = 5,                /* a HIP runtime call or kernel launch failed             */
     ASW_ERR_ALLOC = 6,
@@ -92,7 +92,7 @@ int asw_device_count(void);
  * (min_d + index), like the reference's CV_32FC1 result.  Per-method literals are the
  * selector's (gamma_c=30, gamma_g=20; eps=1e-6; rateS=rateR=10).
  * cost_volume_out (optional, may be NULL): aggregated cost volume, [n][rows][cols] f32 with
- * n = num_d (+1 for ADAPTIVE_WEIGHT and GEODESIC, whose range is inclusive, M.cpp:1021,1447). */
+ * n = num_d (+1 for ADAPTIVE_WEIGHT, 8DIRECT and GEODESIC, whose range is inclusive, M.cpp:1021,1171,1447). */
 int asw_stereo_match(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                      int disparity_type, int algorithm, int win_size, int min_disparity, int num_disparity,
                      float* cost_volume_out);
@@ -111,6 +111,12 @@ int asw_get_timing(asw_ctx* ctx, asw_timing* out);
 int asw_aggregate_bilateral(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                             double gamma_c, double gamma_g, int disparity_type, int win_size,
                             int min_disparity, int num_disparity, float* cost_volume_out);
+/* computeAdaptiveWeight_direct8, M.h:135-136, M.cpp:1167-1319: the classic scheme on row + column + main diagonal of the
+ * window, gamma_c = 30, gamma_g = win*2/3 (integer division).  DISPARITY_LEFT only: the reference's RIGHT branch indexes
+ * its weight vectors with a negative tap coordinate (M.cpp:1291-1295) -> ASW_ERR_UNSUPPORTED_LAYOUT. */
+int asw_aggregate_direct8(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                          int disparity_type, int win_size, int min_disparity, int num_disparity,
+                          float* cost_volume_out);
 /* computeAdaptiveWeight_geodesic, M.h:142-143, M.cpp:1436-1534 */
 int asw_aggregate_geodesic(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                            int disparity_type, int win_size, int min_disparity, int num_disparity,

@@ -1066,6 +1066,70 @@ int orc_asw_blo1(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type
 }
 
 /* ---------------------------------------------------------------------------------------
+ * computeAdaptiveWeight_direct8, M.cpp:1167-1319.
+ * The classic scheme on a sparse support: only the taps with i==j, i==0, j==0 or i+j==ks-1 (M.cpp:1201, 1245) -- the
+ * last test was meant to be the anti-diagonal but only ever matches (h,h), so the support is row + column + main
+ * diagonal = 3*(ks-1) taps.  gamma_c = 30, gamma_g = winSize*2/3 in INTEGER arithmetic (M.cpp:1175), k = 3.
+ * Weight maps are built and consumed in the same order (no transposition here, unlike the classic method).
+ * Range inclusive: minD..minD+numD (M.cpp:1171,1223).  DISPARITY_RIGHT indexes the weight vectors with the signed
+ * tap coordinate i (M.cpp:1291-1295) -- undefined behaviour in the reference -> ORC_ERR_UNSUPPORTED_LAYOUT here.
+ * vol (optional): (float)E, numD+1 planes.
+ * ------------------------------------------------------------------------------------- */
+int orc_asw_direct8(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int disp_type, int win, int minD, int numD,
+                    float* disp, float* vol)
+{
+    if (disp_type != DISPARITY_LEFT) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* build decision, as for the classic method */
+    const int ks = win, h = ks / 2;
+    const int max_offset = minD + numD, min_offset = minD;
+    const double k = 3, gamma_c = 30, gamma_g = (double)(win * 2 / 3);
+    int nt = 0;
+    int* ti = (int*)malloc(sizeof(int) * (size_t)(ks * ks + 1));
+    int* tj = (int*)malloc(sizeof(int) * (size_t)(ks * ks + 1));
+    for (int j = -h; j < h + 1; j++)
+        for (int i = -h; i < h + 1; i++) {
+            if (i == 0 && j == 0) continue;
+            if (i == j || i == 0 || j == 0 || (i + j) == ks - 1) { ti[nt] = i; tj[nt] = j; nt++; }
+        }
+    /* weight of tap t for colour distance dc: the map entry of M.cpp:1214-1215 as a function of (t, dc) */
+    float* lut = (float*)malloc(sizeof(float) * 256 * (size_t)(nt > 0 ? nt : 1));
+    for (int t = 0; t < nt; t++) {
+        double delta_g = sqrt((double)(ti[t] * ti[t] + tj[t] * tj[t]));
+        for (int dc = 0; dc < 256; dc++) lut[t * 256 + dc] = (float)(k * exp(-((double)dc / gamma_c + delta_g / gamma_g)));
+    }
+    uint8_t* left = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* right = (uint8_t*)malloc((size_t)H * W);
+    orc_bgr2gray(Lbgr, H, W, left);
+    orc_bgr2gray(Rbgr, H, W, right);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double best = DBL_MAX;
+            float bd = 0.0f; /* never-written pixels: 0 (the reference leaves them uninitialised) */
+            for (int offset = min_offset; offset <= max_offset; offset++) {
+                double numerator = 0, denominator = 0;
+                const int xr = imax(0, x - offset);
+                for (int t = 0; t < nt && t < 4 * (ks - 1); t++) {
+                    const int i = ti[t], j = tj[t];
+                    const int nx = imin(imax(0, x + i), W - 1), ny = imin(imax(0, y + j), H - 1);
+                    const int nxr = imin(imax(0, xr + i), W - 1);
+                    float a = lut[t * 256 + absdiff_u8(left[(size_t)ny * W + nx], left[(size_t)y * W + x])];
+                    float b = lut[t * 256 + absdiff_u8(right[(size_t)ny * W + nxr], right[(size_t)y * W + xr])];
+                    float ab = a * b;
+                    numerator += ab * fabs((double)(left[(size_t)ny * W + nx] - right[(size_t)ny * W + imax(0, nx - offset)]));
+                    denominator += ab;
+                }
+                double E = numerator / denominator;
+                if (vol) vol[((size_t)(offset - min_offset) * H + y) * W + x] = (float)E;
+                if (E < best) { best = E; bd = (float)offset; }
+            }
+            disp[(size_t)y * W + x] = bd;
+        }
+    free(ti); free(tj); free(lut); free(left); free(right);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
  * stereoMatching selector, M.cpp:46-88, with the literals it hard-codes.
  * ------------------------------------------------------------------------------------- */
 int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int disparity_type, int algorithm, int win,
@@ -1073,6 +1137,7 @@ int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int di
 {
     switch (algorithm) {
     case 2: return orc_asw_classic(L, R, H, W, 30, 20, disparity_type, win, minD, numD, disp, NULL);  /* M.cpp:58 */
+    case 3: return orc_asw_direct8(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:61 */
     case 4: return orc_asw_geodesic(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:64 */
     case 6: return orc_asw_blo1(L, R, H, W, disparity_type, 0.015, win, minD, numD, disp, NULL);       /* M.cpp:70 */
     case 7: return orc_asw_guided(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);      /* M.cpp:73 */

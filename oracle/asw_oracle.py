@@ -180,6 +180,10 @@ def asw_classic(L, R, gamma_c=30.0, gamma_g=20.0, disp_type=0, win=15, minD=0, n
                 minD, numD)
 
 
+def asw_direct8(L, R, disp_type=0, win=15, minD=0, numD=64, want_vol=False):
+    return _agg(lib().orc_asw_direct8, L, R, numD + 1, want_vol, disp_type, win, minD, numD)
+
+
 def geodesic_dist(img, win=15, iters=3):
     img, H, W, _ = _hwc(img)
     out, po = _out((H, W, win, win), np.float32)

@@ -109,11 +109,38 @@ def test_error_behaviour(ctx):
     assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
     assert ctx.stereoMatching(L, R[:, :30], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) is None
     assert asw.last_status() == asw.ERR_SIZE_MISMATCH
-    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID,
-                A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.NCC):
+    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.NCC):
         with pytest.raises(asw.AswError) as e:
             ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
         assert e.value.status == asw.ERR_UNSUPPORTED_METHOD
+
+
+# ---------------------------------------------------------------- direct8
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [
+    (24, 40, 5, 0, 8, 3), (37, 130, 7, 0, 20, 4), (20, 70, 15, 2, 33, 5), (12, 64, 3, 0, 80, 6), (64, 96, 35, 0, 16, 7),
+    (10, 12, 1, 0, 3, 8)])
+def test_direct8_parity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_direct8(L, R, 0, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_direct8(L, R, LEFT, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD + 1, H, W)
+    assert np.array_equal(v_got, v_want, equal_nan=True)   # same tap order -> E bit-identical
+    assert np.array_equal(d_got, d_want)
+
+
+def test_direct8_selector_shift_and_errors(ctx, oracle):
+    d0 = 5
+    L, R = shifted_pair(40, 64, d0)
+    d = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_8DIRECT, 7, 0, 8)
+    assert (d[8:-8, 16:-8] == d0).all()
+    assert np.array_equal(d, oracle.stereo_matching(L, R, 0, 3, 7, 0, 8)[1])
+    with pytest.raises(asw.AswError) as e:      # M.cpp:1291-1295: negative vector index in the reference
+        ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT_8DIRECT, 7, 0, 8)
+    assert e.value.status == asw.ERR_UNSUPPORTED_LAYOUT
+    assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_8DIRECT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
+    # the classic tables must come back after a direct8 call (shared table cache)
+    a = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8)
+    assert np.array_equal(a, oracle.stereo_matching(L, R, 0, 2, 7, 0, 8)[1])
 
 
 # ---------------------------------------------------------------- TAD C+G similarity, SAD cost

@@ -283,6 +283,7 @@ def test_guided_filter_properties(oracle):
 def test_selector_literals(oracle):
     L, R, _ = make_pair(20, 32, 6, seed=11, block=10)
     for alg, direct in [(2, lambda: oracle.asw_classic(L, R, 30, 20, 0, 5, 0, 6)),
+                        (3, lambda: oracle.asw_direct8(L, R, 0, 5, 0, 6)),
                         (4, lambda: oracle.asw_geodesic(L, R, 0, 5, 0, 6)),
                         (7, lambda: oracle.asw_guided(L, R, 0, 1e-6, 5, 0, 6)),
                         (8, lambda: oracle.asw_guided2(L, R, 0, 1e-6, 5, 0, 6)),
@@ -291,8 +292,60 @@ def test_selector_literals(oracle):
         assert rc == 0 and np.array_equal(d, direct()[1]), alg
     rc, d = oracle.stereo_matching(L, R, 0, 6, 5, 0, 6)
     assert rc == 0 and np.array_equal(d, oracle.asw_blo1(L, R, 0, 0.015, 5, 0, 6)[1])
-    for alg in (0, 1, 3, 5, 9, 11):
+    for alg in (0, 1, 5, 9, 11):
         assert oracle.stereo_matching(L, R, 0, alg, 5, 0, 6)[0] == oracle.ERR_UNSUPPORTED_METHOD
+
+
+def _direct8_numpy(L, R, win, minD, numD):
+    """Independent (pure-Python) restatement of M.cpp:1167-1275 for tiny inputs: materialises the weight maps like the
+    reference does and consumes them by the running `count` index."""
+    import math
+    H, W = L.shape[:2]
+    gl, gr = [a.astype(np.int64) for a in (oracle_gray(L), oracle_gray(R))]
+    h = win // 2
+    gamma_c, gamma_g, k = 30.0, float(win * 2 // 3), 3.0
+    taps = [(i, j) for j in range(-h, h + 1) for i in range(-h, h + 1)
+            if not (i == 0 and j == 0) and (i == j or i == 0 or j == 0 or i + j == win - 1)]
+    wl = np.zeros((len(taps), H, W), np.float32)
+    wr = np.zeros((len(taps), H, W), np.float32)
+    for t, (i, j) in enumerate(taps):
+        dg = math.sqrt(i * i + j * j)
+        for y in range(H):
+            for x in range(W):
+                nx, ny = min(max(0, x + i), W - 1), min(max(0, y + j), H - 1)
+                wl[t, y, x] = k * math.exp(-(abs(gl[ny, nx] - gl[y, x]) / gamma_c + dg / gamma_g))
+                wr[t, y, x] = k * math.exp(-(abs(gr[ny, nx] - gr[y, x]) / gamma_c + dg / gamma_g))
+    vol = np.zeros((numD + 1, H, W), np.float64)
+    for o in range(minD, minD + numD + 1):
+        for y in range(H):
+            for x in range(W):
+                num = den = 0.0
+                for t, (i, j) in enumerate(taps):
+                    nx, ny = min(max(0, x + i), W - 1), min(max(0, y + j), H - 1)
+                    ab = np.float32(wl[t, y, x] * wr[t, y, max(0, x - o)])
+                    num += float(ab) * abs(float(gl[ny, nx] - gr[ny, max(0, nx - o)]))
+                    den += float(ab)
+                vol[o - minD, y, x] = num / den if den != 0 else float("nan")
+    return taps, vol
+
+
+def oracle_gray(img):
+    import oracle.asw_oracle as orc
+    return orc.bgr2gray(img)
+
+
+def test_direct8_support_and_values(oracle):
+    # f4 / M.cpp:1201: support = row + column + MAIN diagonal only (the `i + j == ks - 1` test never adds a tap)
+    L, R, _ = make_pair(7, 9, 3, seed=5, block=4)
+    taps, want = _direct8_numpy(L, R, 5, 1, 3)
+    assert len(taps) == 3 * (5 - 1) and (-2, 2) not in taps and (2, 2) in taps
+    rc, d, v = oracle.asw_direct8(L, R, 0, 5, 1, 3, want_vol=True)
+    assert rc == 0 and v.shape == (4, 7, 9)          # inclusive range (M.cpp:1171,1223)
+    assert np.array_equal(v, want.astype(np.float32))
+    assert np.array_equal(d, (np.argmin(want, axis=0) + 1).astype(np.float32))
+    # gamma_g = winSize*2/3 in integer arithmetic: win 5 -> 3, not 3.33 (changes every weight off the centre)
+    assert oracle.asw_direct8(L, R, 1, 5, 1, 3)[0] == oracle.ERR_UNSUPPORTED_LAYOUT   # RIGHT: UB in the reference
+    assert oracle.asw_direct8(L, R, 0, 4, 1, 3)[0] == oracle.ERR_EVEN_WINDOW
 
 
 def test_blo1_quirks(oracle):
