@@ -25,7 +25,8 @@ __all__ = [
     "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
     "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
     "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
-    "stereoMatchingBatch", "computeAdaptiveWeight_BLO1", "computeAdaptiveWeight_direct8",
+    "stereoMatchingBatch", "computeAdaptiveWeight_BLO1", "computeAdaptiveWeight_direct8", "computeNCC", "computeNCC_costs",
+    "computeAdaptiveWeight_GuidedF_3",
     "AswError",
 ]
 
@@ -180,6 +181,29 @@ class Context:
                                         minDisparity=186, numDisparity=144, return_cost_volume=False):
         return self._aggregate(self._lib.asw_aggregate_guided2, "asw_aggregate_guided2", numDisparity, leftImg, rightImg,
                                (int(dispType), float(eps), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeAdaptiveWeight_GuidedF_3(self, leftImg, rightImg, dispType=DISPARITY_LEFT, eps=1e-6, winSize=35,
+                                        minDisparity=186, numDisparity=144, return_cost_volume=False):
+        """M.h:174-176, M.cpp:3063-3137: NCC costs + guided filter."""
+        return self._aggregate(self._lib.asw_aggregate_guided3, "asw_aggregate_guided3", numDisparity, leftImg, rightImg,
+                               (int(dispType), float(eps), winSize, minDisparity, numDisparity), return_cost_volume)
+
+    def computeNCC(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=0, numDisparity=30):
+        """computeNCC -> disparity (M.h:122-123, M.cpp:812-913)."""
+        li, la = _image(leftImg)
+        ri, ra = _image(rightImg)
+        disp = np.zeros((la.shape[0], la.shape[1]), np.float32)
+        di, _ = _image(disp, 5)
+        rc = self._lib.asw_ncc_disparity(self._h, C.byref(li), C.byref(ri), C.byref(di), int(dispType), winSize, minDisparity,
+                                         numDisparity)
+        return disp if self._finish(rc, "asw_ncc_disparity") else None
+
+    def computeNCC_costs(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=0, numDisparity=30,
+                         normalized=True):
+        """computeNCC -> cost_ds (M.h:124-126, M.cpp:924-1013); normalized=False returns the planes before normalize()."""
+        a = np.asarray(leftImg)
+        return self._cost(self._lib.asw_cost_ncc, "asw_cost_ncc", leftImg, rightImg, np.float32, a.shape[:2], numDisparity,
+                          (int(dispType), winSize, minDisparity, numDisparity, int(bool(normalized))))
 
     def computeAdaptiveWeight_BLO1(self, leftImg, rightImg, dispType=DISPARITY_LEFT, sampleRateR=10, winSize=35,
                                    minDisparity=186, numDisparity=144, return_cost_volume=False):
@@ -351,6 +375,9 @@ computeSimilarity = _bind("computeSimilarity")
 getCostSAD = _bind("getCostSAD")
 computeAdaptiveWeight = _bind("computeAdaptiveWeight")
 computeAdaptiveWeight_direct8 = _bind("computeAdaptiveWeight_direct8")
+computeAdaptiveWeight_GuidedF_3 = _bind("computeAdaptiveWeight_GuidedF_3")
+computeNCC = _bind("computeNCC")
+computeNCC_costs = _bind("computeNCC_costs")
 computeAdaptiveWeight_geodesic = _bind("computeAdaptiveWeight_geodesic")
 getGeodesicDist = _bind("getGeodesicDist")
 getGuidedFilter = _bind("getGuidedFilter")

@@ -16,7 +16,8 @@ ABI_SYMBOLS = [
     "asw_stereo_match", "asw_upload_pair", "asw_match_resident", "asw_download_disparity",
     "asw_download_volume", "asw_synchronize", "asw_get_timing",
     "asw_aggregate_bilateral", "asw_aggregate_geodesic", "asw_aggregate_guided", "asw_aggregate_guided2",
-    "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_direct8",
+    "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_direct8", "asw_aggregate_guided3",
+    "asw_cost_ncc", "asw_ncc_disparity",
     "asw_cost_ad", "asw_cost_tad", "asw_cost_similarity", "asw_cost_sad",
     "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray",
     "asw_stereo_match_batch",
@@ -74,6 +75,9 @@ def lib():
         l.asw_aggregate_bilateral.argtypes = [P, IMG, IMG, IMG, D, D, I, I, I, I, P]
         l.asw_aggregate_geodesic.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P]
         l.asw_aggregate_direct8.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P]
+        l.asw_aggregate_guided3.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
+        l.asw_cost_ncc.argtypes = [P, IMG, IMG, P, I, I, I, I, I]
+        l.asw_ncc_disparity.argtypes = [P, IMG, IMG, IMG, I, I, I, I]
         l.asw_aggregate_guided.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_aggregate_guided2.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P]

@@ -375,16 +375,96 @@ static int build_similarity_volume(asw_ctx* ctx, const uint8_t* dL, const uint8_
                              cost, ord_scratch, scales);
 }
 
-static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume, bool variant2)
+// ------------------------------------------------------------------------------------------
+// NCC cost (computeNCC / getInputImgNCC, M.cpp:767-1013): gray images, box means, window sums of squares, then k_ncc
+// ------------------------------------------------------------------------------------------
+static int run_ncc_cost(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int W, int disparity_type, int win, int minD,
+                        int numD, float* vol /* optional, un-normalised */, float* disp /* optional */, int nwta,
+                        int channels = 3)
 {
+    if (win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:828-831, 939-942
+    if (win < 1 || win > 63) return ASW_ERR_BAD_ARGUMENT;
+    const bool right = disparity_type == ASW_DISPARITY_RIGHT;
+    const int max_off = minD + numD - 1, Wp = W + max_off;
+    const size_t plane = (size_t)H * W, pplane = (size_t)H * Wp;
+    DevBuf& g0 = ctx->buf("ncc_gray_ref");
+    DevBuf& g1 = ctx->buf("ncc_gray_oth");
+    DevBuf& gp = ctx->buf("ncc_gray_pad");
+    DevBuf& m0 = ctx->buf("ncc_mean_ref");
+    DevBuf& m1 = ctx->buf("ncc_mean_oth");
+    DevBuf& s0 = ctx->buf("ncc_ss_ref");
+    DevBuf& s1 = ctx->buf("ncc_ss_oth");
+    ASW_TRY(g0.ensure(plane)); ASW_TRY(g1.ensure(plane)); ASW_TRY(gp.ensure(pplane));
+    ASW_TRY(m0.ensure(plane * 4)); ASW_TRY(m1.ensure(pplane * 4));
+    ASW_TRY(s0.ensure(plane * 8)); ASW_TRY(s1.ensure(pplane * 8));
+    // COLOR_RGB2GRAY on BGR data (M.cpp:835,840); reference image = left (LEFT) or right (RIGHT)
+    if (channels == 3) {
+        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dR : dL, H, W, g0.as<uint8_t>()));
+        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dL : dR, H, W, g1.as<uint8_t>()));
+    } else {  // single-channel input is used as it is (M.cpp:833-841: cvtColor only for 3 channels)
+        ASW_HIP_TRY(hipMemcpyAsync(g0.p, right ? dR : dL, plane, hipMemcpyDeviceToDevice, ctx->stream));
+        ASW_HIP_TRY(hipMemcpyAsync(g1.p, right ? dL : dR, plane, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // the other image is padded by max_offset REFLECT columns: on the left (LEFT, M.cpp:852) / on the right (RIGHT, M.cpp:882)
+    ASW_TRY(launch_pad_gray(ctx->stream, g1.as<uint8_t>(), H, W, right ? 0 : max_off, right ? max_off : 0, gp.as<uint8_t>()));
+    ASW_TRY(launch_box_mean_u8(ctx->stream, g0.as<uint8_t>(), H, W, win, m0.as<float>()));   // M.cpp:785-786
+    ASW_TRY(launch_box_mean_u8(ctx->stream, gp.as<uint8_t>(), H, Wp, win, m1.as<float>()));
+    ASW_TRY(launch_ncc_selfsum(ctx->stream, g0.as<uint8_t>(), m0.as<float>(), H, W, win, s0.as<double>()));
+    ASW_TRY(launch_ncc_selfsum(ctx->stream, gp.as<uint8_t>(), m1.as<float>(), H, Wp, win, s1.as<double>()));
+    NccLaunch a;
+    a.gref = g0.as<uint8_t>(); a.mref = m0.as<float>(); a.sref = s0.as<double>();
+    a.goth = gp.as<uint8_t>(); a.moth = m1.as<float>(); a.soth = s1.as<double>();
+    a.H = H; a.W = W; a.Wp = Wp; a.win = win; a.minD = minD; a.numD = numD; a.right = right ? 1 : 0; a.nwta = nwta;
+    a.vol = vol; a.disp = disp;
+    return launch_ncc(ctx->stream, a);
+}
+
+// computeNCC -> disparity (M.cpp:812-913): candidates minD .. max_offset-1 only, the SMALLEST cost wins (LEFT);
+// DISPARITY_RIGHT compares `cost > DBL_MAX`: nothing is ever written -> zeros here (reference: uninitialised Mat).
+static int run_ncc(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+{
+    if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;
+    const int H = f->rows, W = f->cols;
+    const size_t plane = (size_t)H * W;
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = 0;
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (mp.disparity_type == ASW_DISPARITY_RIGHT) {
+        ASW_HIP_TRY(hipMemsetAsync(f->disp.p, 0, plane * 4, ctx->stream));
+        if (keep_volume) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    } else {
+        float* vol = nullptr;
+        if (keep_volume) {  // raw (un-normalised) costs of all numD offsets, for inspection
+            ASW_TRY(f->vol.ensure(plane * mp.numD * 4));
+            f->vol_floats = plane * mp.numD;
+            vol = f->vol.as<float>();
+        }
+        ASW_TRY(run_ncc_cost(ctx, f->L.as<uint8_t>(), f->R.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, mp.numD, vol,
+                             f->disp.as<float>(), mp.numD - 1));
+    }
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->timing.aggregate_launches = 1;
+    return ASW_OK;
+}
+
+enum GuidedKind { GUIDED_SAD6 = 0 /* GuidedF */, GUIDED_SIM3 = 1 /* GuidedF_2 */, GUIDED_NCC = 2 /* GuidedF_3 */ };
+
+static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume, int kind)
+{
+    const bool variant2 = kind == GUIDED_SIM3;
+    // GuidedF_3 + DISPARITY_RIGHT: getGuidedFilter receives the plain right image (M.cpp:3110), a 3-channel guide
+    const bool ncc = kind == GUIDED_NCC, plain3 = variant2 || (ncc && mp.disparity_type == ASW_DISPARITY_RIGHT);
+
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
     // GuidedF_2: RIGHT / gray branches of computeSimilarity throw in the reference (App. B-7).
     if (variant2 && mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
     if (mp.disparity_type != ASW_DISPARITY_LEFT && mp.disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
     const bool right = mp.disparity_type == ASW_DISPARITY_RIGHT;
-    if (!variant2 && mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // getCostSAD_d, M.cpp:2458-2462
+    if (!variant2 && mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // getCostSAD_d, M.cpp:2458-2462; computeNCC, M.cpp:939-942
     if (mp.win < 1 || mp.win > 128) return ASW_ERR_BAD_ARGUMENT;
-    const int H = f->rows, W = f->cols, n = mp.numD, C = variant2 ? 3 : 6;
+    const int H = f->rows, W = f->cols, n = mp.numD, C = plain3 ? 3 : 6;
     const size_t plane = (size_t)H * W;
     DevBuf& raw = ctx->buf("g_raw");
     DevBuf& ord = ctx->buf("g_ord");
@@ -394,7 +474,7 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     DevBuf& ab = ctx->buf("g_ab");
     DevBuf& pxa = ctx->buf("bgrxL");
     DevBuf& pxb = ctx->buf("bgrxR");
-    const int nstat = variant2 ? 1 : n;
+    const int nstat = plain3 ? 1 : n;
     ASW_TRY(raw.ensure(plane * n * 4));
     DevBuf& parts = ctx->buf("g_parts");
     ASW_TRY(parts.ensure(similarity_parts_words(H, W, n) * 4));
@@ -413,11 +493,25 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
 
     GuidedLaunch a;
     // guide = [L, R shifted by -d] (LEFT, M.cpp:2907-2912) or [L shifted by +d, R] (RIGHT, M.cpp:2925-2929)
-    a.shiftA = (!variant2 && right) ? 1 : 0; a.shiftB = (!variant2 && !right) ? -1 : 0; a.C = C; a.guide_per_slice = variant2 ? 0 : 1;
-    ASW_TRY(launch_pack_words(ctx->stream, dL, H, W, 3, 0, pxa.as<uint32_t>()));
-    if (!variant2) ASW_TRY(launch_pack_words(ctx->stream, dR, H, W, 3, 0, pxb.as<uint32_t>()));
-    a.guideA = pxa.as<uint32_t>(); a.guideB = variant2 ? nullptr : pxb.as<uint32_t>();
-    if (variant2) {
+    a.shiftA = (!plain3 && right) ? 1 : 0; a.shiftB = (!plain3 && !right) ? -1 : 0; a.C = C; a.guide_per_slice = plain3 ? 0 : 1;
+    const uint8_t* dGuide3 = variant2 ? dL : dR;  // the 3-channel guide: left image (GuidedF_2) / right image (GuidedF_3 RIGHT)
+    ASW_TRY(launch_pack_words(ctx->stream, plain3 ? dGuide3 : dL, H, W, 3, 0, pxa.as<uint32_t>()));
+    if (!plain3) ASW_TRY(launch_pack_words(ctx->stream, dR, H, W, 3, 0, pxb.as<uint32_t>()));
+    a.guideA = pxa.as<uint32_t>(); a.guideB = plain3 ? nullptr : pxb.as<uint32_t>();
+    if (ncc) {
+        // costs_ds of computeNCC (M.cpp:3076): raw planes, then normalize(NORM_MINMAX) of every plane in place
+        ASW_TRY(run_ncc_cost(ctx, dL, dR, H, W, mp.disparity_type, mp.win, mp.minD, n, raw.as<float>(), nullptr, 0));
+        ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));
+        ASW_TRY(launch_apply_scales(ctx->stream, raw.as<float>(), n, plane, psc.as<float2>()));
+        if (plain3) {
+            ASW_TRY(launch_u8_scale(ctx->stream, dGuide3, plane * 3, ord.as<uint32_t>() + 2 * n, gsc.as<float2>()));
+        } else {
+            DevBuf& colmm = ctx->buf("g_colmm");
+            ASW_TRY(colmm.ensure((size_t)2 * W * sizeof(int)));
+            ASW_TRY(launch_guide_scales_lr(ctx->stream, dL, dR, H, W, mp.minD, n, mp.disparity_type, ord.as<uint32_t>() + 2 * n,
+                                           colmm.as<int>(), gsc.as<float2>()));
+        }
+    } else if (variant2) {
         ASW_TRY(build_similarity_volume(ctx, dL, dR, H, W, mp.minD, n, 0.4, 10, 50, raw.as<float>(), parts.as<uint32_t>(),
                                         psc.as<float2>()));  // M.cpp:2990 (+ the min/max of M.cpp:2775, fused)
         ASW_TRY(launch_u8_scale(ctx->stream, dL, plane * 3, ord.as<uint32_t>() + 2 * n, gsc.as<float2>()));
@@ -444,7 +538,7 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->timing.aggregate_launches = variant2 ? 4 : 5;
+    ctx->timing.aggregate_launches = plain3 ? 4 : 5;
     return ASW_OK;
 }
 
@@ -632,8 +726,10 @@ static int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& 
     case ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT: rc = run_bilateral(ctx, f, mp, keep_volume, true); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC: rc = run_geodesic(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_BLO1: rc = run_blo1(ctx, f, mp, keep_volume); break;
-    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, false); break;
-    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, true); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, GUIDED_SAD6); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, GUIDED_SIM3); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_3: rc = run_guided(ctx, f, mp, keep_volume, GUIDED_NCC); break;
+    case ASW_ALG_NCC: rc = run_ncc(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN: rc = run_wmedian(ctx, f, mp, keep_volume); break;
     default: rc = ASW_ERR_UNSUPPORTED_METHOD; break;
     }
@@ -890,6 +986,56 @@ extern "C" int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image
     ASW_HIP_TRY(hipMemcpyAsync(cost, raw.p, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
+}
+
+extern "C" int asw_cost_ncc(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity_type,
+                            int win_size, int min_disparity, int num_disparity, int normalized)
+{
+    if (!ctx || !cost) return ASW_ERR_BAD_ARGUMENT;
+    ASW_TRY(check_pair(left, right));
+    if (win_size % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:939-942
+    if (num_disparity <= 0 || min_disparity < 0 || win_size < 1 || win_size > 63) return ASW_ERR_BAD_ARGUMENT;
+    if (left->channels != 3 && left->channels != 1) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (disparity_type != ASW_DISPARITY_LEFT && disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const int H = left->rows, W = left->cols, n = num_disparity;
+    const size_t plane = (size_t)H * W;
+    DevBuf& dl = ctx->buf("stageL");
+    DevBuf& dr = ctx->buf("stageR");
+    DevBuf& raw = ctx->buf("g_raw");
+    ASW_TRY(upload_image(ctx, left, dl));
+    ASW_TRY(upload_image(ctx, right, dr));
+    ASW_TRY(raw.ensure(plane * n * 4));
+    ASW_TRY(run_ncc_cost(ctx, dl.as<uint8_t>(), dr.as<uint8_t>(), H, W, disparity_type, win_size, min_disparity, n, raw.as<float>(),
+                         nullptr, 0, left->channels));
+    if (normalized) {  // normalize(curCost_, curCost_norm, 0, 1, NORM_MINMAX), M.cpp:981-983
+        DevBuf& ord = ctx->buf("g_ord");
+        DevBuf& psc = ctx->buf("g_pscales");
+        ASW_TRY(ord.ensure((size_t)(2 * n + 2) * 4));
+        ASW_TRY(psc.ensure((size_t)n * sizeof(float2)));
+        ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));
+        ASW_TRY(launch_apply_scales(ctx->stream, raw.as<float>(), n, plane, psc.as<float2>()));
+    }
+    ASW_HIP_TRY(hipMemcpyAsync(cost, raw.p, plane * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
+extern "C" int asw_ncc_disparity(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp, int disparity_type,
+                                 int win_size, int min_disparity, int num_disparity)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
+    return match_host(ctx, left, right, disp, ASW_ALG_NCC, mp, nullptr);
+}
+
+extern "C" int asw_aggregate_guided3(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                     int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
+                                     float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_3, mp, cost_volume_out);
 }
 
 extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const float* p, float* q, int r, double eps)

@@ -66,6 +66,8 @@ struct asw_ctx {
 
 // ---- kernel launchers (each returns an asw_status; all work is enqueued on `s`) ----
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray);
+// cvtColor(COLOR_RGB2GRAY) applied to BGR data, as computeNCC does (M.cpp:835,840): the R and B coefficients swap
+int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray);
 int launch_cost_ad(hipStream_t s, const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type, int minD,
                    int numD, int do_thresh /* 0: AD, 1: TAD mask */, int threshold, uint8_t* cost);
 int launch_wta(hipStream_t s, const float* vol, int n, int H, int W, int minD, float* disp);
@@ -103,6 +105,24 @@ int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t*
                            int disp_type, uint32_t* ord_scratch, int* colmm_scratch /* 2W */, float2* scales /* numD */);
 
 // ---- box means / guided filter (k_guided.hip) ----
+// ---- NCC cost (k_ncc.hip), computeNCC / getInputImgNCC, M.cpp:767-1013 ----
+struct NccLaunch {
+    const uint8_t* gref;  // reference gray image [H][W]
+    const float* mref;    // its box means
+    const double* sref;   // its window sums of squares
+    const uint8_t* goth;  // other gray image, REFLECT-padded to [H][Wp]
+    const float* moth;
+    const double* soth;
+    int H, W, Wp, win, minD, numD, right, nwta;
+    float* vol;   // optional [numD][H][W], un-normalised
+    float* disp;  // optional [H][W], WTA over the first nwta candidates
+};
+int launch_pad_gray(hipStream_t s, const uint8_t* g, int H, int W, int padL, int padR, uint8_t* out);
+int launch_box_mean_u8(hipStream_t s, const uint8_t* img, int H, int W, int win, float* mean);  // boxFilter(8U -> 32F)
+int launch_ncc_selfsum(hipStream_t s, const uint8_t* g, const float* mean, int H, int W, int win, double* ss);
+int launch_ncc(hipStream_t s, const NccLaunch& a);
+int launch_apply_scales(hipStream_t s, float* vol, int n, size_t plane, const float2* scales);
+
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost);
 struct GuidedLaunch {

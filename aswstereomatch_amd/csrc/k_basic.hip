@@ -11,7 +11,7 @@ __device__ __forceinline__ int reflect_idx(int p, int len)
 }
 
 // cvtColor(COLOR_BGR2GRAY) 8U, OpenCV 4.1.0 14-bit fixed point (M.cpp:1031-1033; App. A-1)
-__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray)
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray, uint32_t k0, uint32_t k2)
 {
     // 4 pixels per thread: 12 input bytes (3 dwords), 1 output dword
     int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -25,14 +25,14 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __re
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t g = (b[3 * k] * 1868u + b[3 * k + 1] * 9617u + b[3 * k + 2] * 4899u + 8192u) >> 14;
+            uint32_t g = (b[3 * k] * k0 + b[3 * k + 1] * 9617u + b[3 * k + 2] * k2 + 8192u) >> 14;
             out |= g << (8 * k);
         }
         *reinterpret_cast<uint32_t*>(gray + i) = out;
     } else {
         for (; i < n; i++) {
             const uint8_t* q = bgr + (size_t)i * 3;
-            gray[i] = (uint8_t)((q[0] * 1868u + q[1] * 9617u + q[2] * 4899u + 8192u) >> 14);
+            gray[i] = (uint8_t)((q[0] * k0 + q[1] * 9617u + q[2] * k2 + 8192u) >> 14);
         }
     }
 }
@@ -141,7 +141,16 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gr
 {
     int n = H * W;
     int threads = 256, blocks = (n / 4 + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray);
+    hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 1868u, 4899u);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
+int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray)
+{
+    int n = H * W;
+    int threads = 256, blocks = (n / 4 + 1 + threads - 1) / threads;
+    hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 4899u, 1868u);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

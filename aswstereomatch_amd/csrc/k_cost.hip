@@ -250,20 +250,21 @@ __global__ __launch_bounds__(256) void k_slice_minmax(const float* __restrict__ 
     const float* p = vol + (size_t)k * plane;
     uint32_t lo = 0xffffffffu, hi = 0u;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // NaN entries (0/0 NCC costs of flat windows) are skipped, like the ordered comparisons of minMaxIdx skip them
+    auto take = [&](float v) {
+        const uint32_t o = f2ord(v);
+        const bool nan = v != v;
+        lo = min(lo, nan ? 0xffffffffu : o);
+        hi = max(hi, nan ? 0u : o);
+    };
     if ((plane & 3) == 0) {
         const float4* p4 = reinterpret_cast<const float4*>(p);
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane / 4; i += stride) {
             float4 v = p4[i];
-            uint32_t a = f2ord(v.x), b = f2ord(v.y), c = f2ord(v.z), d = f2ord(v.w);
-            lo = min(min(lo, a), min(b, min(c, d)));
-            hi = max(max(hi, a), max(b, max(c, d)));
+            take(v.x); take(v.y); take(v.z); take(v.w);
         }
     } else {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += stride) {
-            uint32_t o = f2ord(p[i]);
-            lo = min(lo, o);
-            hi = max(hi, o);
-        }
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += stride) take(p[i]);
     }
     block_minmax_commit(lo, hi, ord + 2 * k);
 }

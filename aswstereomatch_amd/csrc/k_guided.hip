@@ -380,6 +380,14 @@ struct SadSrc {
     }
     __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)abs(r.a - r.b); }
 };
+// plain 8U plane as f32 (boxFilter(8U -> CV_32F) of getInputImgNCC, M.cpp:785-786)
+struct U8Src {
+    const uint8_t* img;
+    int W;
+    struct Raw { int v; };
+    __device__ __forceinline__ Raw fetch(int y, int x, int) const { return Raw{(int)img[(size_t)y * W + x]}; }
+    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)r.v; }
+};
 struct PlaneDst {
     float* out;
     int H, W;
@@ -559,6 +567,13 @@ int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, 
     SadSrc src{gl, gr, W, minD, disp_type};
     PlaneDst dst{cost, H, W};
     return launch_walk<1>(s, src, dst, H, W, win, numD);
+}
+
+int launch_box_mean_u8(hipStream_t s, const uint8_t* img, int H, int W, int win, float* mean)
+{
+    U8Src src{img, W};
+    PlaneDst dst{mean, H, W};
+    return launch_walk<1>(s, src, dst, H, W, win, 1);
 }
 
 int launch_guided(hipStream_t s, const GuidedLaunch& a)

@@ -186,6 +186,24 @@ inline void computeSimilarity(AswMat leftImg, AswMat rightImg, std::vector<AswMa
     }, "computeSimilarity(padded)");
 }
 
+// M.h:122-123: computeNCC -> disparity
+inline AswMat computeNCC(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, int winSize = 7,
+                         int minDisparity = 0, int numDisparity = 30)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_ncc_disparity(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity);
+    }, "computeNCC");
+}
+
+// M.h:124-126: computeNCC -> min-max normalised cost planes
+inline void computeNCC(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_ds, DisparityType dispType = DISPARITY_LEFT,
+                       int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{
+    asw::detail::cost_volume<float>(leftImg, rightImg, cost_ds, numDisparity, ASW_32F, 0, [&](asw_ctx* c, asw_image* l, asw_image* r, float* v) {
+        return asw_cost_ncc(c, l, r, v, (int)dispType, winSize, minDisparity, numDisparity, 1);
+    }, "computeNCC(costs)");
+}
+
 // M.h:133-134
 inline AswMat computeAdaptiveWeight(AswMat leftImg, AswMat rightImg, double gamma_c = 30, double gamma_g = 2,
                                     DisparityType dispType = DISPARITY_LEFT, int winSize = 7, int minDisparity = 186,
@@ -212,6 +230,15 @@ inline AswMat computeAdaptiveWeight_geodesic(AswMat leftImg, AswMat rightImg, Di
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
         return asw_aggregate_geodesic(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
     }, "computeAdaptiveWeight_geodesic");
+}
+
+// M.h:174-176
+inline AswMat computeAdaptiveWeight_GuidedF_3(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 1e-6,
+                                              int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_guided3(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_GuidedF_3");
 }
 
 // M.h:157-159

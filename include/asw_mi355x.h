@@ -30,7 +30,7 @@ typedef enum asw_status {
     ASW_OK = 0,
     ASW_ERR_SIZE_MISMATCH = 1,      /* M.cpp:217-220, 313-316, 430-433: silent return          */
     ASW_ERR_EVEN_WINDOW = 2,        /* M.cpp:654-657, 1440-1443, 2458-2462, 3238-3241: Mat()  */
-    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,5,9,11)          */
+    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,5)               */
     ASW_ERR_UNSUPPORTED_LAYOUT = 4, /* where the reference throws cv::Exception (SURVEY B-7)  */
     ASW_ERR_HIP = 5,                /* a HIP runtime call or kernel launch failed             */
     ASW_ERR_ALLOC = 6,
@@ -129,6 +129,11 @@ int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* r
 int asw_aggregate_guided2(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
                           float* cost_volume_out);
+/* computeAdaptiveWeight_GuidedF_3, M.h:172-174, M.cpp:3063-3137: normalised NCC planes (computeNCC, M.cpp:924-1013) filtered
+ * with the 6-channel guide [L, R shifted by d] (LEFT) or with the plain right image (RIGHT, M.cpp:3110) */
+int asw_aggregate_guided3(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                          int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
+                          float* cost_volume_out);
 /* computeAdaptiveWeight_BLO1, M.h:157-159, M.cpp:2505-2725 (min_disparity must be 0: the reference indexes its
  * per-key slices with the absolute offset) */
 int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
@@ -154,6 +159,16 @@ int asw_cost_similarity(asw_ctx* ctx, const asw_image* left, const asw_image* ri
 /* getCostSAD_d for every d as called from M.cpp:2884-2898: box mean of gray abs-diff */
 int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost,
                  int disparity_type, int win_size, int min_disparity, int num_disparity);
+
+/* computeNCC, volume overload, M.h:121-122, M.cpp:924-1013: cost = sum(l*r) / (sum(l*l)*sum(r*r)) on mean-removed windows of
+ * the RGB2GRAY images; normalized != 0: every plane min-max normalised as the reference stores it, 0: the raw planes.
+ * 1- or 3-channel 8U input. */
+int asw_cost_ncc(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity_type,
+                 int win_size, int min_disparity, int num_disparity, int normalized);
+/* computeNCC, disparity overload, M.h:119-120, M.cpp:812-913 (enum NCC = 11): offsets min_d .. min_d+num_d-2, smallest cost
+ * wins (LEFT); DISPARITY_RIGHT never writes a pixel in the reference -> all zeros here. */
+int asw_ncc_disparity(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp, int disparity_type,
+                      int win_size, int min_disparity, int num_disparity);
 
 /* ---- building blocks that are public in the reference header ---- */
 /* getGuidedFilter, M.h:165, M.cpp:2766-2854: guide 8U with 3 or 6 channels, p/q f32 rows x cols */

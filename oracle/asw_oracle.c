@@ -740,8 +740,10 @@ int orc_guided_filter(const uint8_t* guide, int C, const float* P_in, int H, int
     }
     /* M.cpp:2775: per-call (= per disparity slice) min/max of P */
     {
-        float mn = P_in[0], mx = P_in[0];
-        for (size_t i = 1; i < N; i++) { if (P_in[i] < mn) mn = P_in[i]; if (P_in[i] > mx) mx = P_in[i]; }
+        /* NaN entries (they only arise from the NCC costs of GuidedF_3: 0/0 on flat windows) are skipped, as
+         * minMaxIdx's ordered comparisons skip them; an all-NaN slice gives min = +inf, max = -inf -> scale 0 */
+        float mn = INFINITY, mx = -INFINITY;
+        for (size_t i = 0; i < N; i++) { if (P_in[i] < mn) mn = P_in[i]; if (P_in[i] > mx) mx = P_in[i]; }
         float sa, sb;
         minmax_scale((double)mn, (double)mx, &sa, &sb);
         for (size_t i = 0; i < N; i++) P[i] = P_in[i] * sa + sb;
@@ -840,6 +842,181 @@ int orc_asw_guided(const uint8_t* L, const uint8_t* R, int H, int W, int disp_ty
         rc = orc_guided_filter(guide, 6, costs + (size_t)i * N, H, W, win, eps, qv + (size_t)i * N);
     }
     if (rc == ORC_OK) orc_wta(qv, numD, H, W, minD, disp);
+    free(costs); free(guide);
+    if (!vol) free(qv);
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * NCC cost, computeNCC (both overloads) + getInputImgNCC, M.cpp:767-1013, and computeAdaptiveWeight_GuidedF_3,
+ * M.cpp:3063-3137.
+ *  - gray conversion is COLOR_RGB2GRAY on BGR data (M.cpp:835,840,948,953): the R and B coefficients swap;
+ *  - support window of (y,x): REFLECT-padded gray image (as f32) minus the box mean at (y,x); the box mean is
+ *    boxFilter's default BORDER_REFLECT_101 -- the two borders differ (M.cpp:782-786);
+ *  - the "other" image is padded by max_offset REFLECT columns first (left side for DISPARITY_LEFT, right side for
+ *    DISPARITY_RIGHT) and windows / means are taken on that padded image (M.cpp:852-857, 882-887);
+ *  - cost = sum(l*r) / (sum(l*l) * sum(r*r)): NO square root (M.cpp:867-868); products in f32 (Mat::mul), sums in f64.
+ *    The order in which cv::sum adds the 225 products cannot be verified offline: restated row-major;
+ *  - volume overload: every offset minD..max_offset, each plane cast to f32 and min-max normalised (M.cpp:968-983);
+ *  - disparity overload: offsets minD..max_offset-1 only (M.cpp:864: `<`), DISPARITY_LEFT keeps the SMALLEST cost,
+ *    DISPARITY_RIGHT compares `cost > DBL_MAX`, never true: the reference returns uninitialised memory, 0 here.
+ * ------------------------------------------------------------------------------------- */
+void orc_rgb2gray(const uint8_t* bgr, int H, int W, uint8_t* gray)
+{
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899, shift = 14; /* channel 0 is taken for R */
+    for (long i = 0; i < (long)H * W; i++) {
+        int r = bgr[3 * i], g = bgr[3 * i + 1], b = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (shift - 1))) >> shift);
+    }
+}
+
+typedef struct { int H, W; uint8_t* g; float* mean; double* ss; } ncc_img_t; /* gray image, box means, sum of squares */
+
+/* window element (r,c) of getInputImgNCC's support window at (y,x): REFLECT border, f32 subtraction (M.cpp:782-795) */
+static inline float ncc_elem(const ncc_img_t* im, int y, int x, int r, int c, int h)
+{
+    const int yy = reflect_idx(y - h + r, im->H), xx = reflect_idx(x - h + c, im->W);
+    return (float)im->g[(size_t)yy * im->W + xx] - im->mean[(size_t)y * im->W + x];
+}
+
+static int ncc_prepare(ncc_img_t* im, const uint8_t* gray, int H, int W, int padL, int padR, int win)
+{
+    const int Wp = W + padL + padR, h = win / 2;
+    im->H = H; im->W = Wp;
+    im->g = (uint8_t*)malloc((size_t)H * Wp);
+    im->mean = (float*)malloc((size_t)H * Wp * sizeof(float));
+    im->ss = (double*)malloc((size_t)H * Wp * sizeof(double));
+    float* f = (float*)malloc((size_t)H * Wp * sizeof(float));
+    if (!im->g || !im->mean || !im->ss || !f) { free(f); return ORC_ERR_ALLOC; }
+    for (int y = 0; y < H; y++)
+        for (int c = 0; c < Wp; c++) { /* copyMakeBorder(..., BORDER_REFLECT), M.cpp:852,882 */
+            im->g[(size_t)y * Wp + c] = gray[(size_t)y * W + reflect_idx(c - padL, W)];
+            f[(size_t)y * Wp + c] = (float)im->g[(size_t)y * Wp + c];
+        }
+    box_filter_plane(f, 1, im->mean, 1, H, Wp, win); /* boxFilter(src, CV_32FC1, Size(win,win)), M.cpp:785-786 */
+    free(f);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < Wp; x++) {
+            double s = 0;
+            for (int r = 0; r < win; r++)
+                for (int c = 0; c < win; c++) { float v = ncc_elem(im, y, x, r, c, h); float p = v * v; s += (double)p; }
+            im->ss[(size_t)y * Wp + x] = s;
+        }
+    return ORC_OK;
+}
+static void ncc_free(ncc_img_t* im) { free(im->g); free(im->mean); free(im->ss); }
+
+static inline double ncc_cost(const ncc_img_t* ref, int y, int x, const ncc_img_t* oth, int xo, int win)
+{
+    const int h = win / 2;
+    double s = 0;
+    for (int r = 0; r < win; r++)
+        for (int c = 0; c < win; c++) {
+            float p = ncc_elem(ref, y, x, r, c, h) * ncc_elem(oth, y, xo, r, c, h); /* Mat::mul on CV_32F */
+            s += (double)p;
+        }
+    return s / (ref->ss[(size_t)y * ref->W + x] * oth->ss[(size_t)y * oth->W + xo]);
+}
+
+/* raw = 0: the volume overload (M.cpp:924-1013), numD planes, f32, each min-max normalised;
+ * raw = 1: the same planes before normalize() (what the GPU parity tests also look at). */
+int orc_cost_ncc(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int disp_type, int win, int minD, int numD, int raw,
+                 float* cost)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* M.cpp:939-942 */
+    if (disp_type != DISPARITY_LEFT && disp_type != DISPARITY_RIGHT) return ORC_OK; /* no branch taken */
+    const int max_offset = minD + numD - 1;
+    const size_t N = (size_t)H * W;
+    uint8_t* gl = (uint8_t*)malloc(N);
+    uint8_t* gr = (uint8_t*)malloc(N);
+    orc_rgb2gray(Lbgr, H, W, gl);
+    orc_rgb2gray(Rbgr, H, W, gr);
+    ncc_img_t ref, oth;
+    int rc;
+    if (disp_type == DISPARITY_LEFT) { rc = ncc_prepare(&ref, gl, H, W, 0, 0, win); if (!rc) rc = ncc_prepare(&oth, gr, H, W, max_offset, 0, win); }
+    else { rc = ncc_prepare(&ref, gr, H, W, 0, 0, win); if (!rc) rc = ncc_prepare(&oth, gl, H, W, 0, max_offset, win); }
+    if (rc) return rc;
+    for (int offset = minD; offset <= max_offset; offset++) {
+        float* plane = cost + (size_t)(offset - minD) * N;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const int xo = disp_type == DISPARITY_LEFT ? x + max_offset - offset : x + offset; /* M.cpp:975, 1002 */
+                plane[(size_t)y * W + x] = (float)ncc_cost(&ref, y, x, &oth, xo, win);
+            }
+        if (!raw) { /* normalize(curCost_, curCost_norm, 0, 1, NORM_MINMAX), M.cpp:981-983 */
+            float mn = INFINITY, mx = -INFINITY;
+            for (size_t i = 0; i < N; i++) { if (plane[i] < mn) mn = plane[i]; if (plane[i] > mx) mx = plane[i]; }
+            float sa, sb;
+            minmax_scale((double)mn, (double)mx, &sa, &sb);
+            for (size_t i = 0; i < N; i++) plane[i] = plane[i] * sa + sb;
+        }
+    }
+    ncc_free(&ref); ncc_free(&oth); free(gl); free(gr);
+    return ORC_OK;
+}
+
+/* computeNCC -> disparity, M.cpp:812-913 */
+int orc_ncc_disparity(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int disp_type, int win, int minD, int numD,
+                      float* disp)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* M.cpp:828-831 */
+    const int max_offset = minD + numD - 1;
+    const size_t N = (size_t)H * W;
+    for (size_t i = 0; i < N; i++) disp[i] = 0.0f; /* never-written pixels: 0 (reference: uninitialised Mat) */
+    if (disp_type != DISPARITY_LEFT) return ORC_OK;  /* RIGHT: `cost_d > DBL_MAX` never holds (M.cpp:896) */
+    uint8_t* gl = (uint8_t*)malloc(N);
+    uint8_t* gr = (uint8_t*)malloc(N);
+    orc_rgb2gray(Lbgr, H, W, gl);
+    orc_rgb2gray(Rbgr, H, W, gr);
+    ncc_img_t ref, oth;
+    int rc = ncc_prepare(&ref, gl, H, W, 0, 0, win);
+    if (!rc) rc = ncc_prepare(&oth, gr, H, W, max_offset, 0, win);
+    if (rc) return rc;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double best = DBL_MAX;
+            for (int offset = minD; offset < max_offset; offset++) { /* exclusive upper bound, M.cpp:864 */
+                double c = ncc_cost(&ref, y, x, &oth, x + max_offset - offset, win);
+                if (c < best) { best = c; disp[(size_t)y * W + x] = (float)offset; }
+            }
+        }
+    ncc_free(&ref); ncc_free(&oth); free(gl); free(gr);
+    return ORC_OK;
+}
+
+/* computeAdaptiveWeight_GuidedF_3, M.cpp:3063-3137: normalised NCC planes filtered with the 6-channel guide
+ * [L, R shifted by d] (LEFT, M.cpp:3085-3096) or with the plain right image (RIGHT: the 6-channel guide is built but
+ * `rightImg` is what getGuidedFilter receives, M.cpp:3100-3112). */
+int orc_asw_guided3(const uint8_t* L, const uint8_t* R, int H, int W, int disp_type, double eps, int win, int minD,
+                    int numD, float* disp, float* vol)
+{
+    if (win % 2 == 0) return ORC_ERR_EVEN_WINDOW; /* computeNCC returns without costs, costs_ds[i] then throws */
+    if (disp_type != DISPARITY_LEFT && disp_type != DISPARITY_RIGHT) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    const size_t N = (size_t)H * W;
+    float* costs = (float*)malloc((size_t)numD * N * sizeof(float));
+    float* qv = vol ? vol : (float*)malloc((size_t)numD * N * sizeof(float));
+    uint8_t* guide = (uint8_t*)malloc(N * 6);
+    if (!costs || !qv || !guide) { free(costs); if (!vol) free(qv); free(guide); return ORC_ERR_ALLOC; }
+    int rc = orc_cost_ncc(L, R, H, W, disp_type, win, minD, numD, 0, costs);
+    for (int i = 0; i < numD && rc == ORC_OK; i++) {
+        if (disp_type == DISPARITY_LEFT) {
+            const int d = minD + i; /* Rect(numDisparity-i-1) on a pad of max_offset columns == shift by minD+i */
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    const uint8_t* pl = L + ((size_t)y * W + x) * 3;
+                    const uint8_t* pr = R + ((size_t)y * W + reflect_idx(x - d, W)) * 3;
+                    uint8_t* g = guide + ((size_t)y * W + x) * 6;
+                    g[0] = pl[0]; g[1] = pl[1]; g[2] = pl[2]; g[3] = pr[0]; g[4] = pr[1]; g[5] = pr[2];
+                }
+            rc = orc_guided_filter(guide, 6, costs + (size_t)i * N, H, W, win, eps, qv + (size_t)i * N);
+        } else {
+            rc = orc_guided_filter(R, 3, costs + (size_t)i * N, H, W, win, eps, qv + (size_t)i * N);
+        }
+    }
+    if (rc == ORC_OK) orc_wta(qv, numD, H, W, minD, disp); /* M.cpp:3116-3134 */
     free(costs); free(guide);
     if (!vol) free(qv);
     return rc;
@@ -1142,7 +1319,9 @@ int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int di
     case 6: return orc_asw_blo1(L, R, H, W, disparity_type, 0.015, win, minD, numD, disp, NULL);       /* M.cpp:70 */
     case 7: return orc_asw_guided(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);      /* M.cpp:73 */
     case 8: return orc_asw_guided2(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);     /* M.cpp:76 */
+    case 9: return orc_asw_guided3(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);     /* M.cpp:79 */
     case 10: return orc_asw_wmedian(L, R, H, W, disparity_type, win, 10, 10, minD, numD, disp, NULL);  /* M.cpp:82 */
+    case 11: return orc_ncc_disparity(L, R, H, W, disparity_type, win, minD, numD, disp);              /* M.cpp:85 */
     default: return 3; /* unsupported method (out of scope) */
     }
 }

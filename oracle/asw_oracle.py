@@ -75,6 +75,14 @@ def bgr2gray(img):
     return out
 
 
+def rgb2gray(img):
+    img, p = _u8(img)
+    H, W, _ = img.shape
+    out, po = _out((H, W), np.uint8)
+    lib().orc_rgb2gray(p, H, W, po)
+    return out
+
+
 def _hwc(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     if img.ndim == 2:
@@ -209,6 +217,26 @@ def asw_guided2(L, R, disp_type=0, eps=1e-6, win=15, minD=0, numD=64, want_vol=F
 
 def asw_guided(L, R, disp_type=0, eps=1e-6, win=15, minD=0, numD=64, want_vol=False):
     return _agg(lib().orc_asw_guided, L, R, numD, want_vol, disp_type, C.c_double(eps), win, minD, numD)
+
+
+def cost_ncc(L, R, disp_type=0, win=15, minD=0, numD=30, raw=False):
+    L, H, W, _ = _hwc(L)
+    R, pr = _u8(R)
+    out, po = _out((numD, H, W), np.float32)
+    rc = lib().orc_cost_ncc(L.ctypes.data_as(C.c_void_p), pr, H, W, disp_type, win, minD, numD, int(bool(raw)), po)
+    return rc, out
+
+
+def ncc_disparity(L, R, disp_type=0, win=15, minD=0, numD=30):
+    L, H, W, _ = _hwc(L)
+    R, pr = _u8(R)
+    out, po = _out((H, W), np.float32)
+    rc = lib().orc_ncc_disparity(L.ctypes.data_as(C.c_void_p), pr, H, W, disp_type, win, minD, numD, po)
+    return rc, out
+
+
+def asw_guided3(L, R, disp_type=0, eps=1e-6, win=15, minD=0, numD=64, want_vol=False):
+    return _agg(lib().orc_asw_guided3, L, R, numD, want_vol, disp_type, C.c_double(eps), win, minD, numD)
 
 
 def asw_blo1(L, R, disp_type=0, sampleRateR=0.015, win=15, minD=0, numD=64, want_vol=False):

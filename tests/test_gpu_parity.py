@@ -109,7 +109,7 @@ def test_error_behaviour(ctx):
     assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
     assert ctx.stereoMatching(L, R[:, :30], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) is None
     assert asw.last_status() == asw.ERR_SIZE_MISMATCH
-    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.NCC):
+    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_BILATERAL_GRID):
         with pytest.raises(asw.AswError) as e:
             ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
         assert e.value.status == asw.ERR_UNSUPPORTED_METHOD
@@ -141,6 +141,51 @@ def test_direct8_selector_shift_and_errors(ctx, oracle):
     # the classic tables must come back after a direct8 call (shared table cache)
     a = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8)
     assert np.array_equal(a, oracle.stereo_matching(L, R, 0, 2, 7, 0, 8)[1])
+
+
+# ---------------------------------------------------------------- NCC cost, NCC disparity, GuidedF_3
+@pytest.mark.parametrize("H,W,dt,win,minD,numD,seed", [
+    (9, 16, 0, 3, 0, 4, 1), (37, 70, 0, 7, 0, 24, 2), (20, 33, 0, 15, 3, 9, 3), (6, 10, 0, 5, 0, 25, 4),
+    (37, 70, 1, 7, 0, 24, 5), (20, 133, 1, 5, 2, 18, 6), (12, 64, 0, 1, 0, 3, 7)])
+def test_cost_ncc(ctx, oracle, H, W, dt, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=8)
+    rc, want = oracle.cost_ncc(L, R, dt, win, minD, numD, raw=True)
+    got = np.stack(ctx.computeNCC_costs(L, R, dt, win, minD, numD, normalized=False))
+    assert rc == 0 and got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True)     # same summation order -> bit-identical
+    rc, want = oracle.cost_ncc(L, R, dt, win, minD, numD)
+    got = np.stack(ctx.computeNCC_costs(L, R, dt, win, minD, numD))
+    assert np.array_equal(got, want, equal_nan=True)
+    # single-channel input: used as it is (no colour conversion)
+    g = oracle.rgb2gray(L), oracle.rgb2gray(R)
+    got1 = np.stack(ctx.computeNCC_costs(g[0], g[1], dt, win, minD, numD))
+    assert np.array_equal(got1, got, equal_nan=True)
+
+
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(24, 40, 5, 0, 8, 3), (37, 130, 7, 0, 20, 4), (20, 70, 15, 2, 33, 5)])
+def test_ncc_disparity(ctx, oracle, H, W, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, want = oracle.ncc_disparity(L, R, 0, win, minD, numD)
+    got = ctx.computeNCC(L, R, LEFT, win, minD, numD)
+    assert rc == 0 and np.array_equal(got, want)
+    assert got.max() <= minD + numD - 2                  # the last offset is never tested (M.cpp:864)
+    assert np.array_equal(ctx.stereoMatching(L, R, LEFT, A.NCC, win, minD, numD), want)
+    right = ctx.computeNCC(L, R, RIGHT, win, minD, numD)  # `cost > DBL_MAX` never holds (M.cpp:896): nothing written
+    assert (right == 0).all() and np.array_equal(right, oracle.ncc_disparity(L, R, 1, win, minD, numD)[1])
+    assert ctx.computeNCC(L, R, LEFT, 6, minD, numD) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
+
+
+@pytest.mark.parametrize("H,W,dt,win,minD,numD,seed", [(24, 40, 0, 5, 0, 8, 3), (40, 270, 0, 15, 0, 12, 4), (30, 100, 0, 7, 2, 9, 5),
+                                                     (24, 40, 1, 5, 0, 8, 6), (30, 100, 1, 7, 2, 9, 7)])
+def test_guided3_parity(ctx, oracle, H, W, dt, win, minD, numD, seed):
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=16)
+    rc, d_want, v_want = oracle.asw_guided3(L, R, dt, 1e-6, win, minD, numD, want_vol=True)
+    d_got, v_got = ctx.computeAdaptiveWeight_GuidedF_3(L, R, dt, 1e-6, win, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v_got.shape == (numD, H, W)
+    assert _close(v_got, v_want)             # 1e-4 on the float cost volume
+    assert np.array_equal(d_got, d_want)     # WTA index bit-exact
+    sel = ctx.stereoMatching(L, R, dt, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, win, minD, numD)
+    assert np.array_equal(sel, oracle.stereo_matching(L, R, dt, 9, win, minD, numD)[1])
 
 
 # ---------------------------------------------------------------- TAD C+G similarity, SAD cost

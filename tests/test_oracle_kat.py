@@ -284,6 +284,7 @@ def test_selector_literals(oracle):
     L, R, _ = make_pair(20, 32, 6, seed=11, block=10)
     for alg, direct in [(2, lambda: oracle.asw_classic(L, R, 30, 20, 0, 5, 0, 6)),
                         (3, lambda: oracle.asw_direct8(L, R, 0, 5, 0, 6)),
+                        (9, lambda: oracle.asw_guided3(L, R, 0, 1e-6, 5, 0, 6)),
                         (4, lambda: oracle.asw_geodesic(L, R, 0, 5, 0, 6)),
                         (7, lambda: oracle.asw_guided(L, R, 0, 1e-6, 5, 0, 6)),
                         (8, lambda: oracle.asw_guided2(L, R, 0, 1e-6, 5, 0, 6)),
@@ -292,7 +293,9 @@ def test_selector_literals(oracle):
         assert rc == 0 and np.array_equal(d, direct()[1]), alg
     rc, d = oracle.stereo_matching(L, R, 0, 6, 5, 0, 6)
     assert rc == 0 and np.array_equal(d, oracle.asw_blo1(L, R, 0, 0.015, 5, 0, 6)[1])
-    for alg in (0, 1, 5, 9, 11):
+    rc, d = oracle.stereo_matching(L, R, 0, 11, 5, 0, 6)
+    assert rc == 0 and np.array_equal(d, oracle.ncc_disparity(L, R, 0, 5, 0, 6)[1])
+    for alg in (0, 1, 5):
         assert oracle.stereo_matching(L, R, 0, alg, 5, 0, 6)[0] == oracle.ERR_UNSUPPORTED_METHOD
 
 
@@ -346,6 +349,94 @@ def test_direct8_support_and_values(oracle):
     # gamma_g = winSize*2/3 in integer arithmetic: win 5 -> 3, not 3.33 (changes every weight off the centre)
     assert oracle.asw_direct8(L, R, 1, 5, 1, 3)[0] == oracle.ERR_UNSUPPORTED_LAYOUT   # RIGHT: UB in the reference
     assert oracle.asw_direct8(L, R, 0, 4, 1, 3)[0] == oracle.ERR_EVEN_WINDOW
+
+
+def _ncc_numpy(L, R, win, minD, numD, right=False):
+    """Independent (pure-Python) restatement of getInputImgNCC + computeNCC (M.cpp:767-1013) for tiny inputs: builds
+    the padded images and every support window explicitly, as the reference does."""
+    H, W = L.shape[:2]
+    h, max_off = win // 2, minD + numD - 1
+
+    def gray_rgb(img):   # COLOR_RGB2GRAY applied to BGR data: channel 0 gets the R weight
+        a = img.astype(np.int64)
+        return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+    def windows(g):      # getInputImgNCC: REFLECT-padded f32 windows minus the REFLECT_101 box mean
+        Hh, Ww = g.shape
+        pad = np.pad(g, h, mode="symmetric").astype(np.float32)
+        p101 = np.pad(g.astype(np.float64), h, mode="reflect") if h > 0 else g.astype(np.float64)
+        out = np.zeros((Hh, Ww, win, win), np.float32)
+        for y in range(Hh):
+            for x in range(Ww):
+                mean = np.float32(p101[y:y + win, x:x + win].sum() * (1.0 / (win * win)))
+                out[y, x] = pad[y:y + win, x:x + win] - mean
+        return out
+
+    gl, gr = gray_rgb(L), gray_rgb(R)
+    if not right:
+        ref, oth = windows(gl), windows(np.pad(gr, ((0, 0), (max_off, 0)), mode="symmetric"))
+    else:
+        ref, oth = windows(gr), windows(np.pad(gl, ((0, 0), (0, max_off)), mode="symmetric"))
+    vol = np.zeros((numD, H, W), np.float64)
+    for k in range(numD):
+        off = minD + k
+        for y in range(H):
+            for x in range(W):
+                a = ref[y, x]
+                b = oth[y, x + max_off - off] if not right else oth[y, x + off]
+                s = lambda m: float(np.sum(m.astype(np.float64).ravel()))   # products are f32, the sum is f64
+                den = s(a * a) * s(b * b)
+                vol[k, y, x] = s(a * b) / den if den != 0 else float("nan")
+    return vol
+
+
+def test_ncc_quirks(oracle):
+    L, R, _ = make_pair(8, 11, 3, seed=9, block=4)
+    for right in (False, True):
+        want = _ncc_numpy(L, R, 3, 1, 4, right)
+        rc, raw = oracle.cost_ncc(L, R, int(right), 3, 1, 4, raw=True)
+        assert rc == 0 and raw.shape == (4, 8, 11)
+        # numpy's pairwise summation may differ from the row-major f64 sum in the last bit of the f64 result only
+        assert np.allclose(raw, want.astype(np.float32), rtol=1e-6, atol=0, equal_nan=True)
+        rc, nrm = oracle.cost_ncc(L, R, int(right), 3, 1, 4)
+        for k in range(4):   # normalize(NORM_MINMAX) with float scale/shift, non-fused (App. A-10)
+            mn, mx = np.float64(raw[k].min()), np.float64(raw[k].max())
+            sc = np.float32(1.0 / (mx - mn)); sh = np.float32(0.0 - mn * (1.0 / (mx - mn)))
+            assert np.array_equal(nrm[k], raw[k] * sc + sh)
+    # disparity overload: offsets minD..max_offset-1 only, SMALLEST cost wins (M.cpp:864-875); RIGHT never writes
+    rc, raw = oracle.cost_ncc(L, R, 0, 3, 1, 4, raw=True)
+    rc, d = oracle.ncc_disparity(L, R, 0, 3, 1, 4)
+    want = _ncc_numpy(L, R, 3, 1, 4)
+    assert rc == 0 and set(np.unique(d)) <= {1.0, 2.0, 3.0}            # offset 4 = max_offset is never tested
+    agree = (d == (np.argmin(want[:3], axis=0) + 1)).mean()
+    assert agree > 0.97                                                   # f64 ties aside
+    rc, d = oracle.ncc_disparity(L, R, 1, 3, 1, 4)
+    assert rc == 0 and (d == 0).all()
+    assert oracle.cost_ncc(L, R, 0, 4, 1, 4)[0] == oracle.ERR_EVEN_WINDOW
+    # RGB2GRAY on BGR data: swapping channels 0 and 2 of the input turns it into BGR2GRAY
+    assert np.array_equal(oracle.rgb2gray(L), oracle.bgr2gray(L[..., ::-1].copy()))
+    # flat windows: 0/0 -> NaN costs, never selected (all-NaN column -> 0)
+    Z = np.zeros((6, 8, 3), np.uint8) + 7
+    rc, raw = oracle.cost_ncc(Z, Z, 0, 3, 0, 2, raw=True)
+    assert np.isnan(raw).all() and (oracle.ncc_disparity(Z, Z, 0, 3, 0, 3)[1] == 0).all()
+
+
+def test_guided3_structure(oracle):
+    L, R, _ = make_pair(14, 20, 4, seed=4, block=6)
+    rc, d, v = oracle.asw_guided3(L, R, 0, 1e-6, 5, 1, 4, want_vol=True)
+    assert rc == 0 and v.shape == (4, 14, 20) and np.isfinite(v).all()
+    # it is getGuidedFilter applied to the normalised NCC planes with the 6-channel guide [L, R shifted by d]
+    rc, costs = oracle.cost_ncc(L, R, 0, 5, 1, 4)
+    k, dd = 2, 3
+    idx = np.abs(np.arange(20) - dd); idx = np.where(np.arange(20) - dd < 0, -(np.arange(20) - dd) - 1, np.arange(20) - dd)
+    guide = np.concatenate([L, R[:, idx]], axis=2)
+    rc, q = oracle.guided_filter(guide, costs[k], 5, 1e-6)
+    assert np.array_equal(q, v[k])
+    # RIGHT: the guide handed to getGuidedFilter is the plain right image (M.cpp:3110)
+    rc, d, v = oracle.asw_guided3(L, R, 1, 1e-6, 5, 1, 4, want_vol=True)
+    rc, costs = oracle.cost_ncc(L, R, 1, 5, 1, 4)
+    assert np.array_equal(oracle.guided_filter(R, costs[1], 5, 1e-6)[1], v[1])
+    assert oracle.asw_guided3(L, R, 0, 1e-6, 4, 1, 4)[0] == oracle.ERR_EVEN_WINDOW
 
 
 def test_blo1_quirks(oracle):
