@@ -30,12 +30,18 @@ def main():
     out["similarity"] = O.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1]
     out["sad"] = O.cost_sad(L, R, 0, WIN, 0, D)[1]
     out["geodesic_dist_L"] = O.geodesic_dist(L, WIN, 3)[1]
+    out["ncc_raw"] = O.cost_ncc(L, R, 0, WIN, 0, D, raw=True)[1]
+    out["ncc"] = O.cost_ncc(L, R, 0, WIN, 0, D)[1]
+    out["ncc_disp"] = O.ncc_disparity(L, R, 0, WIN, 0, D)[1]
     for name, fn in [("classic", lambda: O.asw_classic(L, R, 30, 20, 0, WIN, 0, D, want_vol=True)),
                      ("geodesic", lambda: O.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
                      ("guided", lambda: O.asw_guided(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided2", lambda: O.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("wmedian", lambda: O.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True)),
                      ("blo1", lambda: O.asw_blo1(L, R, 0, 0.015, WIN, 0, D, want_vol=True)),
+                     ("direct8", lambda: O.asw_direct8(L, R, 0, WIN, 0, D, want_vol=True)),
+                     ("guided3", lambda: O.asw_guided3(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
+                     ("guided3_right", lambda: O.asw_guided3(L, R, 1, 1e-6, WIN, 0, D, want_vol=True)),
                      ("classic_right", lambda: O.asw_classic(L, R, 30, 20, 1, WIN, 0, D, want_vol=True)),
                      ("geodesic_right", lambda: O.asw_geodesic(L, R, 1, WIN, 0, D, want_vol=True)),
                      ("guided_right", lambda: O.asw_guided(L, R, 1, 1e-6, WIN, 0, D, want_vol=True))]:

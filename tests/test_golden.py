@@ -22,7 +22,13 @@ def test_oracle_reproduces_golden(oracle, gold):
     assert np.array_equal(oracle.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1], gold["similarity"])
     assert np.array_equal(oracle.cost_sad(L, R, 0, WIN, 0, D)[1], gold["sad"])
     assert np.array_equal(oracle.geodesic_dist(L, WIN, 3)[1], gold["geodesic_dist_L"])
+    assert np.array_equal(oracle.cost_ncc(L, R, 0, WIN, 0, D, raw=True)[1], gold["ncc_raw"])
+    assert np.array_equal(oracle.cost_ncc(L, R, 0, WIN, 0, D)[1], gold["ncc"])
+    assert np.array_equal(oracle.ncc_disparity(L, R, 0, WIN, 0, D)[1], gold["ncc_disp"])
     for name, fn in [("classic", lambda: oracle.asw_classic(L, R, 30, 20, 0, WIN, 0, D, want_vol=True)),
+                     ("direct8", lambda: oracle.asw_direct8(L, R, 0, WIN, 0, D, want_vol=True)),
+                     ("guided3", lambda: oracle.asw_guided3(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
+                     ("guided3_right", lambda: oracle.asw_guided3(L, R, 1, 1e-6, WIN, 0, D, want_vol=True)),
                      ("geodesic", lambda: oracle.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
                      ("guided", lambda: oracle.asw_guided(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided2", lambda: oracle.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
@@ -58,12 +64,17 @@ def test_hip_reproduces_golden(gold):
     assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, D)), gold["similarity"])
     assert np.array_equal(np.stack(ctx.getCostSAD(L, R, LEFT, WIN, 0, D)), gold["sad"])
     assert np.array_equal(ctx.getGeodesicDist(L, WIN, 3), gold["geodesic_dist_L"])
-    exact = {"classic": A.ADAPTIVE_WEIGHT, "geodesic": A.ADAPTIVE_WEIGHT_GEODESIC, "wmedian": A.ADAPTIVE_WEIGHT_MEDIAN}
+    assert np.array_equal(np.stack(ctx.computeNCC_costs(L, R, LEFT, WIN, 0, D, normalized=False)), gold["ncc_raw"])
+    assert np.array_equal(np.stack(ctx.computeNCC_costs(L, R, LEFT, WIN, 0, D)), gold["ncc"])
+    assert np.array_equal(ctx.stereoMatching(L, R, LEFT, A.NCC, WIN, 0, D), gold["ncc_disp"])
+    exact = {"classic": A.ADAPTIVE_WEIGHT, "geodesic": A.ADAPTIVE_WEIGHT_GEODESIC, "wmedian": A.ADAPTIVE_WEIGHT_MEDIAN,
+             "direct8": A.ADAPTIVE_WEIGHT_8DIRECT}
     for name, alg in exact.items():
         d, v = ctx.stereoMatching(L, R, LEFT, alg, WIN, 0, D, return_cost_volume=True)
         assert np.array_equal(d, gold[name + "_disp"]), name
         assert np.array_equal(v, gold[name + "_vol"], equal_nan=True), name
-    for name, alg in {"guided": A.ADAPTIVE_WEIGHT_GUIDED_FILTER, "guided2": A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2}.items():
+    for name, alg in {"guided": A.ADAPTIVE_WEIGHT_GUIDED_FILTER, "guided2": A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2,
+                      "guided3": A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3}.items():
         d, v = ctx.stereoMatching(L, R, LEFT, alg, WIN, 0, D, return_cost_volume=True)
         assert np.array_equal(d, gold[name + "_disp"]), name          # WTA index bit-exact
         assert np.abs(v - gold[name + "_vol"]).max() < 1e-4, name      # float cost volume within 1e-4 (north_star)
@@ -73,6 +84,8 @@ def test_hip_reproduces_golden(gold):
         assert np.array_equal(d, gold[name + "_disp"]) and np.array_equal(v, gold[name + "_vol"], equal_nan=True), name
     d, v = ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER, WIN, 0, D, return_cost_volume=True)
     assert np.array_equal(d, gold["guided_right_disp"]) and np.abs(v - gold["guided_right_vol"]).max() < 1e-4
+    d, v = ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, WIN, 0, D, return_cost_volume=True)
+    assert np.array_equal(d, gold["guided3_right_disp"]) and np.abs(v - gold["guided3_right_vol"]).max() < 1e-4
     d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_BLO1, WIN, 0, D, return_cost_volume=True)
     gv = gold["blo1_vol"]
     fin = np.isfinite(gv)
