@@ -628,7 +628,7 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     if (mp.win % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:3238-3241
     if (f->channels != 3) return ASW_ERR_UNSUPPORTED_LAYOUT;
     if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;  // App. B-7 / B-13
-    if (mp.win < 1 || mp.win > 15) return ASW_ERR_BAD_ARGUMENT;  // 256-slot sorting network (win*win <= 256)
+    if (mp.win < 1 || mp.win > 45) return ASW_ERR_BAD_ARGUMENT;  // 256-slot fast network up to 15x15, 64-bit general path up to 2048 slots
     const int H = f->rows, W = f->cols, n = mp.numD, cells = mp.win * mp.win;
     const int max_off = mp.minD + mp.numD - 1, Wb = W + max_off;
     const size_t plane = (size_t)H * W;

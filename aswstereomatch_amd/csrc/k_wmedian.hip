@@ -7,7 +7,8 @@
 // cost of the element BEFORE the crossing one (or the first one), M.cpp:3276-3304 (App. B-13).
 //
 // GPU mapping: one wavefront per pixel, looping over d.  The 225 pairs of a 15x15 window sit 4 per lane
-// (256 slots, padded with max keys / zero weights).  A key made of (order-preserving cost bits, window
+// (256 slots, padded with max keys / zero weights); larger windows (up to 45x45) take the general path k_wmedian_big
+// with 8 / 16 / 32 64-bit keys per lane.  A key made of (order-preserving cost bits, window
 // index) makes a plain bitonic network a STABLE sort: 15 intra-lane and 21 cross-lane compare-exchange
 // steps (DPP / ds_swizzle / bpermute), no payload is moved -- the weight of a sorted element is fetched
 // from LDS by its window index afterwards.  Prefix sums are a per-lane chain plus a
@@ -84,28 +85,37 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v)
 // cross-lane ones select with one of six loop-invariant lane masks (bit 0..5 of the lane id).
 struct LaneMasks { uint32_t m[6]; };  // m[b] = all ones where bit b of the lane id is clear (loop-invariant VGPRs)
 
-template <int LM, int RX, int BITLOG>  // partner = (lane ^ LM, r ^ RX); the lane with bit BITLOG clear is the lower one
-__device__ __forceinline__ void cross_step(uint32_t (&key)[4], const LaneMasks& lm)
+template <int LM>
+__device__ __forceinline__ unsigned long long lane_xor(unsigned long long v)
+{
+    const uint32_t lo = lane_xor<LM>((uint32_t)v), hi = lane_xor<LM>((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// The network is written for KPL keys per lane (element e = lane*KPL + r) of type T (u32: the 256-slot fast path;
+// u64: the general path for windows above 15x15).
+template <int LM, int RX, int BITLOG, class T, int KPL>  // partner = (lane ^ LM, r ^ RX); the lane with bit BITLOG clear is the lower one
+__device__ __forceinline__ void cross_step(T (&key)[KPL], const LaneMasks& lm)
 {
     const bool lower = lm.m[BITLOG] != 0u;
-    uint32_t o[4];
+    T o[KPL];
 #pragma unroll
-    for (int r = 0; r < 4; r++) o[r] = lane_xor<LM>(key[r ^ RX]);
+    for (int r = 0; r < KPL; r++) o[r] = lane_xor<LM>(key[r ^ RX]);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t mn = min(key[r], o[r]), mx = max(key[r], o[r]);
+    for (int r = 0; r < KPL; r++) {
+        const T mn = min(key[r], o[r]), mx = max(key[r], o[r]);
         key[r] = lower ? mn : mx;  // lower lane keeps the minimum, upper lane the maximum
     }
 }
 
-template <int RX>  // intra-lane: pairs (r, r ^ RX)
-__device__ __forceinline__ void local_step(uint32_t (&key)[4])
+template <int RX, class T, int KPL>  // intra-lane: pairs (r, r ^ RX)
+__device__ __forceinline__ void local_step(T (&key)[KPL])
 {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < KPL; r++) {
         const int q = r ^ RX;
         if (q > r) {
-            const uint32_t a = key[r], b = key[q];
+            const T a = key[r], b = key[q];
             key[r] = min(a, b);
             key[q] = max(a, b);
         }
@@ -114,11 +124,11 @@ __device__ __forceinline__ void local_step(uint32_t (&key)[4])
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
-template <int J>  // half-cleaner steps j = J, J/2, ..., 1 (element distance)
-__device__ __forceinline__ void half_cleaners(uint32_t (&key)[4], const LaneMasks& lm)
+template <int J, class T, int KPL>  // half-cleaner steps j = J, J/2, ..., 1 (element distance)
+__device__ __forceinline__ void half_cleaners(T (&key)[KPL], const LaneMasks& lm)
 {
-    if constexpr (J >= 4) {
-        cross_step<J / 4, 0, ilog2(J / 4)>(key, lm);
+    if constexpr (J >= KPL) {
+        cross_step<J / KPL, 0, ilog2(J / KPL)>(key, lm);
         half_cleaners<J / 2>(key, lm);
     } else if constexpr (J >= 1) {
         local_step<J>(key);
@@ -126,22 +136,20 @@ __device__ __forceinline__ void half_cleaners(uint32_t (&key)[4], const LaneMask
     }
 }
 
-template <int K>
-__device__ __forceinline__ void merge_sorted_halves(uint32_t (&key)[4], const LaneMasks& lm)
+template <int K, class T, int KPL>
+__device__ __forceinline__ void merge_sorted_halves(T (&key)[KPL], const LaneMasks& lm)
 {
-    if constexpr (K == 2) {
-        local_step<1>(key);
-    } else if constexpr (K == 4) {
-        local_step<3>(key);  // mirror inside the lane: (0,3) (1,2)
-        half_cleaners<1>(key, lm);
+    if constexpr (K <= KPL) {
+        local_step<K - 1>(key);  // mirror inside the lane: (r, r ^ (K-1))
+        if constexpr (K > 2) half_cleaners<K / 4>(key, lm);
     } else {
-        cross_step<K / 4 - 1, 3, ilog2(K / 8)>(key, lm);  // mirror: lane ^ (K/4-1), register ^ 3
+        cross_step<K / KPL - 1, KPL - 1, ilog2(K / (2 * KPL))>(key, lm);  // mirror: lane ^ (K/KPL-1), register ^ (KPL-1)
         half_cleaners<K / 4>(key, lm);
     }
 }
 
-template <int K>
-__device__ __forceinline__ void bitonic_sort(uint32_t (&key)[4], const LaneMasks& lm)
+template <int K, class T, int KPL>
+__device__ __forceinline__ void bitonic_sort(T (&key)[KPL], const LaneMasks& lm)
 {
     if constexpr (K > 2) bitonic_sort<K / 2>(key, lm);
     merge_sorted_halves<K>(key, lm);
@@ -239,6 +247,91 @@ __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost 
     }
 }
 
+// General path for windows above 15x15 (win*win <= 64*KPL slots): one wavefront per workgroup and pixel, KPL 64-bit keys
+// per lane = (order-preserving cost bits << 32 | window index), the same stable network, the same f64 prefix walk.
+// Nothing per element is kept across candidates (offsets are recomputed), so the register budget is the keys alone.
+template <int KPL>
+__global__ __launch_bounds__(64) void k_wmedian_big(const float* __restrict__ cost, const float* __restrict__ wLd,
+                                                    const float* __restrict__ wRb, int H, int W, int win, int numD, int max_off,
+                                                    float* __restrict__ out)
+{
+    constexpr int SLOTS = 64 * KPL;
+    extern __shared__ __align__(16) unsigned char wm_smem[];
+    unsigned long long* sK = reinterpret_cast<unsigned long long*>(wm_smem);   // [SLOTS] sorted keys
+    float* sW = reinterpret_cast<float*>(wm_smem + (size_t)SLOTS * 8);          // [SLOTS] weights by window index
+    const int lane = threadIdx.x;
+    const size_t pix = blockIdx.x;
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    const int n = win * win, h = win / 2, Wb = W + max_off;
+    const size_t plane = (size_t)H * W;
+    LaneMasks lm;
+#pragma unroll
+    for (int b = 0; b < 6; b++) lm.m[b] = (lane & (1 << b)) ? 0u : 0xffffffffu;
+
+    for (int d = 0; d < numD; d++) {
+        const int cb = x - d + numD - 1;  // weightWinsR[y][x - offset + numDisparity - 1], M.cpp:3274
+        const float* wl = wLd + pix * n;
+        const float* wr = wRb + ((size_t)y * Wb + cb) * n;
+        const float* cp = cost + (size_t)d * plane;
+        unsigned long long key[KPL];
+        double s_loc = 0.0;
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const int e = lane * KPL + r;
+            float w = 0.0f;
+            key[r] = (0xffffffffull << 32) | (uint32_t)e;  // padding slots sort last and weigh nothing (sW[e] = 0)
+            if (e < n) {
+                const int j = e / win, i = e - j * win;
+                const float c = cp[reflect_idx(y + j - h, H) * W + reflect_idx(x + i - h, W)];  // M.cpp:665,3273
+                w = wl[e] * wr[e];  // (wL .mul wd) .mul wR, f32
+                uint32_t u = __float_as_uint(c);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving for any sign
+                key[r] = ((unsigned long long)u << 32) | (uint32_t)e;
+            }
+            s_loc += (double)w;
+            sW[e] = w;
+        }
+        double tot = s_loc;  // cv::sum(weight_img_win)[0] / 2  (f64 accumulation, M.cpp:3284)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        const double half = tot / 2;
+
+        bitonic_sort<SLOTS>(key, lm);
+
+        double run = 0.0;  // lane total of the sorted weights (same-wave LDS: sW was written above in program order)
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            run += (double)sW[(uint32_t)key[r]];
+            sK[lane * KPL + r] = key[r];
+        }
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            double t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        double acc = incl - run;  // exclusive prefix of this lane
+        int first = KPL;
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            acc += (double)sW[(uint32_t)key[r]];
+            if (first == KPL && acc > half) first = r;
+        }
+        const unsigned long long ball = __ballot(first < KPL);
+        float res = 0.0f;
+        if (ball) {
+            const int fl = __ffsll((long long)ball) - 1;
+            const int fr = __shfl(first, fl);
+            const int kpos = fl * KPL + fr;
+            const int take = kpos == 0 ? 0 : kpos - 1;  // predecessor of the crossing element (M.cpp:3293-3301)
+            uint32_t u = (uint32_t)(sK[take] >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            res = __uint_as_float(u);
+        }
+        if (lane == 0) out[(size_t)d * plane + pix] = res;
+    }
+}
+
 }  // namespace
 
 int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,
@@ -253,8 +346,21 @@ int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, 
 int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
                    int max_off, float* out)
 {
-    if (win * win > 256) return ASW_ERR_BAD_ARGUMENT;
     size_t npix = (size_t)H * W;
+    const int n = win * win;
+    if (n > 256) {  // general path: 512 / 1024 / 2048 slots, 64-bit keys
+        if (n > 2048) return ASW_ERR_BAD_ARGUMENT;
+        const int kpl = n <= 512 ? 8 : (n <= 1024 ? 16 : 32);
+        const size_t lds = (size_t)64 * kpl * 12;
+        if (kpl == 8)
+            hipLaunchKernelGGL(k_wmedian_big<8>, dim3((unsigned)npix), dim3(64), lds, s, cost, wLd, wRb, H, W, win, numD, max_off, out);
+        else if (kpl == 16)
+            hipLaunchKernelGGL(k_wmedian_big<16>, dim3((unsigned)npix), dim3(64), lds, s, cost, wLd, wRb, H, W, win, numD, max_off, out);
+        else
+            hipLaunchKernelGGL(k_wmedian_big<32>, dim3((unsigned)npix), dim3(64), lds, s, cost, wLd, wRb, H, W, win, numD, max_off, out);
+        ASW_HIP_TRY(hipGetLastError());
+        return ASW_OK;
+    }
     hipLaunchKernelGGL(k_wmedian, dim3((unsigned)((npix + WM_WAVES - 1) / WM_WAVES)), dim3(256), 0, s, cost, wLd, wRb, H, W, win,
                        numD, max_off, out);
     ASW_HIP_TRY(hipGetLastError());

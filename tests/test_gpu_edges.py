@@ -81,6 +81,16 @@ def test_guided_and_median_small_shapes(ctx, oracle, H, W):
         assert rc == 0 and np.array_equal(v, vw) and np.array_equal(d, dw), ("wm", win)
 
 
+@pytest.mark.parametrize("H,W,win,minD,numD,seed", [(12, 30, 17, 0, 5, 1), (20, 44, 21, 1, 6, 2), (16, 40, 23, 0, 4, 3), (14, 36, 35, 0, 3, 4),
+                                                     (10, 24, 45, 0, 3, 5)])
+def test_weighted_median_large_windows(ctx, oracle, H, W, win, minD, numD, seed):
+    # windows above 15x15 take the general path (512 / 1024 / 2048 slots, 64-bit keys): same stable order, same pick
+    L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=8)
+    rc, dw, vw = oracle.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, win, 10, 10, minD, numD, return_cost_volume=True)
+    assert rc == 0 and np.array_equal(v, vw) and np.array_equal(d, dw)
+
+
 def test_even_guided2_window_is_accepted_like_the_reference(ctx, oracle):
     # GuidedF_2 has no parity check on winSize: boxFilter(Size(6,6)) uses anchor 3 (M.cpp:2976-3006)
     L, R, _ = make_pair(20, 40, 6, seed=3, block=8)
@@ -108,8 +118,8 @@ def test_bad_arguments(ctx):
         assert e.value.status == asw.ERR_BAD_ARGUMENT
     with pytest.raises(TypeError):
         ctx.stereoMatching(L.astype(np.float32), R, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4)
-    with pytest.raises(asw.AswError):   # weighted median above the 256-slot network
-        ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, 17, 0, 4)
+    with pytest.raises(asw.AswError):   # weighted median above the 2048-slot general path
+        ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, 47, 0, 4)
     # non-contiguous (strided) inputs are honoured through asw_image.step
     big = np.zeros((8, 16, 3), np.uint8)
     big[:, ::2] = L
