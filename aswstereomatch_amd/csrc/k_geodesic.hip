@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_planes_to_windows(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // aggregation
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 4, GG = 5;  // tile, taps per staging group; GDC = widest d-chunk of a kernel instance
+constexpr int TW = 64, TH = 4, GG = 8;  // tile, taps per staging group; GDC = widest d-chunk of a kernel instance
 
 struct GeoParams {
     int H, W, win, minD, nD;
@@ -160,10 +160,10 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
     const int win = p.win, h = win / 2, H = p.H, W = p.W;
     const int TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
     constexpr int SWR = TW + DC - 1;
-    // LDS carve-up (sized on the host for DC = GDC).  The colour-L1 cost (<= 765) is kept as u16: 16 B per cell
-    // at DC = 8 -> one ds_read_b128 per tap, and the whole workgroup needs 40 KB -> four workgroups per CU.
-    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);                            // [TR*LW][DC]
-    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);     // [2][GG][TH][TW+GDC-1]
+    // LDS carve-up (sized on the host for DC = GDC).  There is no cost tile: the colour-L1 cost of a tap and candidate is
+    // one v_sad_u8 of two BGRX pixels read from the image tiles (a u16 cost tile was 45 KB at DC = 16 and held the
+    // kernel at two wavefronts per SIMD).
+    float* sWR = reinterpret_cast<float*>(smem);                                 // [2][GG][TH][TW+GDC-1]
     uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + 2 * GG * TH * (TW + GDC - 1));  // [TR][LW]
     uint32_t* sR = sL + TR * LW;                                                 // [TR][RWmax]
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -179,27 +179,19 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
         int yy = min(max(y0 - h + r, 0), H - 1), xx = min(max(sRx0 + c, 0), W - 1);
         sR[r * RWmax + c] = imgR[(size_t)yy * W + (p.flip ? W - 1 - xx : xx)];
     }
-    __syncthreads();
-    // colour-L1 cost tile: C[r][c][dd] = |L(ny,nx) - R(ny, max(0,nx-d))|_1   (M.cpp:1490)
-    for (int i = tid; i < TR * LW; i += 256) {
-        int r = i / LW, c = i - r * LW;
-        int nx = min(max(x0 - h + c, 0), W - 1);
-        uint32_t pl = sL[i];
-#pragma unroll
-        for (int dd = 0; dd < DC; dd++) {
-            int xr = max(0, nx - (d0 + dd));
-            int tc = min(max(xr - sRx0, 0), RW - 1);  // tile is clamp-replicated
-            sC[(size_t)i * DC + dd] = (uint16_t)cdist(pl, sR[r * RWmax + tc]);
-        }
-    }
-
+    // colour-L1 cost of tap (j,i) and candidate dd: |L(ny,nx) - R(ny, max(0,nx-d))|_1 (M.cpp:1490) with nx clamped to the
+    // image.  Tile column of that right pixel: max(tcmin, tc0 - dd), tc0 = nx - d0 - sRx0.  Where nothing clamps (the
+    // tile and its shifted window lie inside the image) this is tx + i + DC-1-dd: DC consecutive LDS words.
+    const bool interior = sRx0 >= 0 && x0 - h >= 0 && x0 + TW + h <= W;
+    const int tcmin = min(max(-sRx0, 0), RW - 1);
     double num[DC], den[DC];
 #pragma unroll
     for (int dd = 0; dd < DC; dd++) { num[dd] = 0.0; den[dd] = 0.0; }
     const int x = x0 + tx, y = y0 + ty;
     const int xc = min(x, W - 1), yc = min(y, H - 1);
     const uint16_t* myWL = wL + (size_t)yc * W + (p.flip ? W - 1 - xc : xc);
-    const uint16_t* myC = sC + (size_t)(ty * LW + tx) * DC;
+    const uint32_t* myL = sL + ty * LW + tx;
+    const uint32_t* myR = sR + ty * RWmax + tx;
     const float* myWR = sWR + ty * (TW + GDC - 1) + tx + (DC - 1);
     const int ntaps = win * win;
 
@@ -259,28 +251,22 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
         for (int tt = 0; tt < GG; tt++) {
             if (tt < ng) {
                 const float wl = wlv[tt];
-                const uint16_t* cell = myC + (size_t)(j * LW + i) * DC;
-                uint32_t cw[(DC + 1) / 2];
-                if constexpr (DC == 16) {
-                    uint4 v = *reinterpret_cast<const uint4*>(cell);
-                    uint4 u = *reinterpret_cast<const uint4*>(cell + 8);
-                    cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-                    cw[4] = u.x; cw[5] = u.y; cw[6] = u.z; cw[7] = u.w;
-                } else if constexpr (DC == 8) {
-                    uint4 v = *reinterpret_cast<const uint4*>(cell);
-                    cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-                } else if constexpr (DC == 4) {
-                    uint2 v = *reinterpret_cast<const uint2*>(cell);
-                    cw[0] = v.x; cw[1] = v.y;
-                } else if constexpr (DC == 2) {
-                    cw[0] = *reinterpret_cast<const uint32_t*>(cell);
+                const uint32_t pl = myL[j * LW + i];
+                uint32_t pr[DC];
+                if (interior) {
+                    const uint32_t* q = myR + j * RWmax + i;
+#pragma unroll
+                    for (int dd = 0; dd < DC; dd++) pr[dd] = q[DC - 1 - dd];
                 } else {
-                    cw[0] = cell[0];
+                    const uint32_t* q = sR + (ty + j) * RWmax;
+                    const int tc0 = min(max(x0 - h + tx + i, 0), W - 1) - d0 - sRx0;
+#pragma unroll
+                    for (int dd = 0; dd < DC; dd++) pr[dd] = q[max(tcmin, tc0 - dd)];
                 }
                 const float* wr = myWR + buf * GSTR + tt * TH * (TW + GDC - 1);
 #pragma unroll
                 for (int dd = 0; dd < DC; dd++) {
-                    float c = (float)((cw[dd >> 1] >> (16 * (dd & 1))) & 0xffffu);
+                    float c = (float)cdist(pl, pr[dd]);
                     float ab = wl * wr[-dd];   // f32
                     float abc = ab * c;        // f32 (M.cpp:1488-1490)
                     num[dd] = num[dd] + (double)abc;
@@ -307,14 +293,14 @@ __device__ __forceinline__ void geo_chunk(const GeoParams& p, const uint32_t* __
 }
 
 template <int GDC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
                                                       const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
                                                       const uint16_t* __restrict__ wR, float* __restrict__ vol,
                                                       float* __restrict__ disp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int h = p.win / 2, TR = TH + 2 * h, LW = TW + 2 * h;
-    float* sWR = reinterpret_cast<float*>(smem + (size_t)TR * LW * GDC * 2);
+    float* sWR = reinterpret_cast<float*>(smem);
     uint32_t* sL = reinterpret_cast<uint32_t*>(sWR + 2 * GG * TH * (TW + GDC - 1));
     const int tid = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     for (int i = tid; i < TR * LW; i += 256) {
@@ -391,7 +377,7 @@ template <int GDC>
 size_t geo_lds_bytes(int win)
 {
     const int h = win / 2, TR = TH + 2 * h, LW = TW + 2 * h, RWmax = TW + 2 * h + GDC - 1;
-    return (size_t)TR * LW * GDC * 2 + (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
+    return (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
 }
 template <int GDC>
 int launch_geo_t(hipStream_t s, const GeoParams& p, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
@@ -412,9 +398,7 @@ int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* img
                         int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp)
 {
     GeoParams p{H, W, win, minD, nD, flip};
-    // widest d-chunk whose cost tile still leaves two workgroups per CU (16 wide: 70 KB at win 15); big windows fall
-    // back to 8-wide chunks (win 35: 103 KB, one workgroup per CU)
-    if (geo_lds_bytes<16>(win) <= 80 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp);
-    if (geo_lds_bytes<8>(win) <= 160 * 1024) return launch_geo_t<8>(s, p, imgL, imgR, wL, wR, vol, disp);
+    // 16-wide d-chunks: 25 KB of LDS at win 15 (45 KB at win 35)
+    if (geo_lds_bytes<16>(win) <= 160 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp);
     return ASW_ERR_BAD_ARGUMENT;
 }
