@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_planes_to_windows(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // aggregation
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 4, GG = 8;  // tile, taps per staging group; GDC = widest d-chunk of a kernel instance
+constexpr int TW = 64, TH = 4, GG = 5;  // tile, taps per staging group; GDC = widest d-chunk of a kernel instance
 
 struct GeoParams {
     int H, W, win, minD, nD;
