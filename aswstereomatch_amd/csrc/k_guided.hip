@@ -405,7 +405,10 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     if (k < 1 || k > SW / 2) return ASW_ERR_BAD_ARGUMENT;  // k-1 halo columns must leave outputs in the strip
     const int XO = SW - (k - 1);
     const int nxw = (W + XO - 1) / XO;
-    int band = 64;  // 48..180 rows measured within +-8 %
+    // rows per band: with the XCD-aware order short bands win for the multi-channel passes although every band pays k-1
+    // warm-up rows (1080p D=128 GuidedF_2, a/b + q pass: 16 rows 5.53 ms, 20..32 rows 5.43-5.50, 48 rows 5.79, 64 rows 6.09,
+    // 128 rows 6.24, 270 rows 8.15); the single-channel launches (SAD cost, BLO1) are best at 64
+    int band = NP >= 4 ? 32 : 64;
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
