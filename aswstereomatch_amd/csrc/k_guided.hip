@@ -42,7 +42,7 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 //   * ND slices per wavefront: operands that do not depend on the slice (guide pixel, guide statistics) are
 //     fetched once -- the ND fetches are issued back to back with identical addresses and merge (CSE).
 template <int NP, int CPL, int ND, int WPE, class Src, class Dst>
-__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices, int ngx, int nby)
+__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
 {
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -54,14 +54,18 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     // equal blockIdx.x % 8 share an L2.  Each XCD takes every 8th region (a band of 4 strips) and runs through ALL
     // slices of it before the next region, so whatever does not depend on the slice (guide pixels, guide statistics)
     // and the halo rows/columns are fetched from HBM once per region and hit in that XCD's L2 afterwards.
-    const int nzg = (nslices + ND - 1) / ND;
+    // The four wavefronts of a workgroup take four strips of one slice group, or (slice_par) one strip of four
+    // consecutive slice groups: they then walk the same rows at the same time and the slice-independent loads of three
+    // of them hit in the CU's L1.
+    const int spw = slice_par ? 4 : 1;
+    const int nzg = ((nslices + ND - 1) / ND + spw - 1) / spw;
     const int wj = blockIdx.x >> 3;
-    const int zg = wj % nzg;
     const int reg = (wj / nzg) * 8 + (blockIdx.x & 7);
     if (reg >= ngx * nby) return;
     const int gx = reg % ngx, by = reg / ngx;
-    const int xw = gx * 4 + wv;  // wavefront's strip index
-    if (xw >= nxw) return;       // whole wavefront exits
+    const int xw = slice_par ? gx : gx * 4 + wv;              // wavefront's strip index
+    const int zg = slice_par ? (wj % nzg) * 4 + wv : wj % nzg;  // wavefront's slice group
+    if (xw >= nxw || zg * ND >= nslices) return;              // whole wavefront exits
     const int xo0 = xw * XO;
     const int c0 = CPL * lane;           // first strip column of this lane
     int kz[ND];
@@ -413,10 +417,14 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
     auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
-    const int ngx = (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = (n + ND - 1) / ND;
+    // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
+    // GuidedF_2 -1 %); four strips of the one slice otherwise
+    const int slice_par = (n + ND - 1) / ND >= 4 ? 1 : 0;
+    const int spw = slice_par ? 4 : 1;
+    const int ngx = slice_par ? nxw : (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = ((n + ND - 1) / ND + spw - 1) / spw;
     const long long nwg = (long long)((ngx * nby + 7) / 8) * 8 * nzg;  // regions rounded up to a multiple of the 8 XCDs
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby, slice_par);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
