@@ -6,8 +6,8 @@
 // accumulating weights in f64 until the partial sum exceeds half of the total weight, and returns the
 // cost of the element BEFORE the crossing one (or the first one), M.cpp:3276-3304 (App. B-13).
 //
-// GPU mapping: one wavefront per pixel, looping over d.  The 225 pairs of a 15x15 window sit 4 per lane
-// (256 slots, padded with max keys / zero weights); larger windows (up to 45x45) take the general path k_wmedian_big
+// GPU mapping: one wavefront per pixel, looping over d two candidates at a time.  The 225 pairs of a 15x15 window sit
+// 8 per lane in one half of the wavefront (256 slots, padded with max keys / zero weights); larger windows (up to 45x45) take the general path k_wmedian_big
 // with 8 / 16 / 32 64-bit keys per lane.  A key made of (order-preserving cost bits, window
 // index) makes a plain bitonic network a STABLE sort: 15 intra-lane and 21 cross-lane compare-exchange
 // steps (DPP / ds_swizzle / bpermute), no payload is moved -- the weight of a sorted element is fetched
@@ -157,93 +157,101 @@ __device__ __forceinline__ void bitonic_sort(T (&key)[KPL], const LaneMasks& lm)
 
 constexpr int WM_WAVES = 4;
 
+// Fast path, win*win <= 256: one wavefront per pixel, TWO candidates at a time -- lanes 0-31 sort the window of candidate
+// d, lanes 32-63 that of d+1, 8 keys per lane.  The network never exchanges across lane bit 5, so the two halves sort
+// independently, 21 of the 36 steps are intra-lane min/max pairs and every cross-lane step is a DPP / ds_swizzle move
+// (no ds_bpermute).
 __global__ __launch_bounds__(256) void k_wmedian(const float* __restrict__ cost /* raw [numD][H][W] */,
                                                  const float* __restrict__ wLd /* [H][W][n] */,
                                                  const float* __restrict__ wRb /* [H][Wb][n] */, int H, int W, int win,
                                                  int numD, int max_off, float* __restrict__ out /* [numD][H][W] */)
 {
-    __shared__ float sW[WM_WAVES][256];
-    __shared__ uint32_t sK[WM_WAVES][256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int KPL = 8;
+    __shared__ float sW[WM_WAVES][2][256];
+    __shared__ uint32_t sK[WM_WAVES][2][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half_id = lane >> 5, l32 = lane & 31;
     const size_t pix = (size_t)blockIdx.x * WM_WAVES + wv;
     if (pix >= (size_t)H * W) return;  // whole wave exits together
     const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
     const int n = win * win, h = win / 2, Wb = W + max_off;
     const size_t plane = (size_t)H * W;
+    float* mW = sW[wv][half_id];
+    uint32_t* mK = sK[wv][half_id];
 
     LaneMasks lm;
 #pragma unroll
     for (int b = 0; b < 6; b++) lm.m[b] = (lane & (1 << b)) ? 0u : 0xffffffffu;
 
-    float wl[4];
-    int off[4];   // offset of the element's cost sample inside a cost plane (REFLECT-padded window, M.cpp:665,3273)
-    int ee[4];    // window index, clamped for the padding slots (their loads are discarded)
-    uint32_t padkey[4];  // 0 for real elements, all ones for padding slots (sorts last, weight 0)
+    float wl[KPL];
+    int off[KPL];  // offset of the element's cost sample inside a cost plane (REFLECT-padded window, M.cpp:665,3273)
+    int ee[KPL];   // window index, clamped for the padding slots (their loads are discarded)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int e = lane * 4 + r;
+    for (int r = 0; r < KPL; r++) {
+        const int e = l32 * KPL + r;
         const bool valid = e < n;
         ee[r] = valid ? e : 0;
-        padkey[r] = valid ? 0u : 0xffffffffu;
         const int j = ee[r] / win, i = ee[r] - j * win;
         off[r] = reflect_idx(y + j - h, H) * W + reflect_idx(x + i - h, W);
         wl[r] = valid ? wLd[pix * n + ee[r]] : 0.0f;
     }
 
-    for (int d = 0; d < numD; d++) {
-        const int cb = x - d + numD - 1;  // weightWinsR[y][x - offset + numDisparity - 1], M.cpp:3274
+    for (int dbase = 0; dbase < numD; dbase += 2) {
+        const int d = dbase + half_id;
+        const bool dvalid = d < numD;
+        const int dc = dvalid ? d : numD - 1;   // the idle half of an odd tail repeats the last candidate and stores nothing
+        const int cb = x - dc + numD - 1;  // weightWinsR[y][x - offset + numDisparity - 1], M.cpp:3274
         const float* wr = wRb + ((size_t)y * Wb + cb) * n;
-        const float* cp = cost + (size_t)d * plane;
-        float w[4];
-        uint32_t key[4];
+        const float* cp = cost + (size_t)dc * plane;
+        uint32_t key[KPL];
         double s_loc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int e = lane * 4 + r;
-            w[r] = wl[r] * wr[ee[r]];  // (wL .mul wd) .mul wR, f32 (0 for padding slots: wl = 0)
-            key[r] = (((__float_as_uint(cp[off[r]]) - COST_BASE_BITS) << 8) | (uint32_t)e) | padkey[r];
-            s_loc += (double)w[r];
-            sW[wv][e] = w[r];
+        for (int r = 0; r < KPL; r++) {
+            const int e = l32 * KPL + r;
+            const float w = wl[r] * wr[ee[r]];  // (wL .mul wd) .mul wR, f32 (0 for padding slots: wl = 0)
+            const uint32_t k = ((__float_as_uint(cp[off[r]]) - COST_BASE_BITS) << 8) | (uint32_t)e;
+            key[r] = e < n ? k : (0xffffff00u | (uint32_t)e);  // padding slots sort last, weight 0
+            s_loc += (double)w;
+            mW[e] = w;
         }
         // cv::sum(weight_img_win)[0] / 2  (f64 accumulation, M.cpp:3284)
         double tot = s_loc;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        for (int o = 16; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         const double half = tot / 2;
 
         bitonic_sort<256>(key, lm);
 
         // weights in sorted order, inclusive prefix sums in f64
-        double pre[4];
+        double pre[KPL];
         double run = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t idx = key[r] & 0xffu;
-            run += (double)sW[wv][idx];   // same-wave LDS: written above by this wave, in program order
+        for (int r = 0; r < KPL; r++) {
+            run += (double)mW[key[r] & 0xffu];   // same-wave LDS: written above by this wave, in program order
             pre[r] = run;
-            sK[wv][lane * 4 + r] = key[r];
+            mK[l32 * KPL + r] = key[r];
         }
-        double incl = run;  // wave inclusive scan of the lane totals
+        double incl = run;  // inclusive scan of the lane totals inside each half
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
+        for (int o = 1; o < 32; o <<= 1) {
             double t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
+            if (l32 >= o) incl += t;
         }
         const double excl = incl - run;
-        int first = 4;
+        int first = KPL;
 #pragma unroll
-        for (int r = 3; r >= 0; r--)
+        for (int r = KPL - 1; r >= 0; r--)
             if (excl + pre[r] > half) first = r;
-        const unsigned long long ball = __ballot(first < 4);
+        const unsigned long long ball = __ballot(first < KPL);
+        const uint32_t mine = (uint32_t)(ball >> (32 * half_id));
         float res = 0.0f;
-        if (ball) {
-            const int fl = __ffsll((long long)ball) - 1;
-            const int fr = __shfl(first, fl);
-            const int kpos = fl * 4 + fr;
+        if (mine) {
+            const int fl = __ffs((int)mine) - 1;
+            const int fr = __shfl(first, fl + 32 * half_id);
+            const int kpos = fl * KPL + fr;
             const int take = kpos == 0 ? 0 : kpos - 1;  // predecessor of the crossing element (M.cpp:3293-3301)
-            res = __uint_as_float((sK[wv][take] >> 8) + COST_BASE_BITS);
+            res = __uint_as_float((mK[take] >> 8) + COST_BASE_BITS);
         }
-        if (lane == 0) out[(size_t)d * plane + pix] = res;
+        if (l32 == 0 && dvalid) out[(size_t)d * plane + pix] = res;
     }
 }
 
