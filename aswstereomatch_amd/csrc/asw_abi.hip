@@ -533,7 +533,9 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
         ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), n, plane, ord.as<uint32_t>(), psc.as<float2>()));  // M.cpp:2775
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = n; a.r = mp.win; a.minD = mp.minD; a.eps = mp.eps;
-    a.stats = stats.as<float>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
+    DevBuf& repb = ctx->buf("g_rep");
+    ASW_TRY(repb.ensure((size_t)n * sizeof(int)));
+    a.stats = stats.as<float>(); a.rep_scratch = repb.as<int>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
@@ -1077,7 +1079,7 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     a.guideA = pxa.as<uint32_t>(); a.guideB = C == 6 ? pxb.as<uint32_t>() : nullptr;
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;
-    a.stats = stats.as<float>(); a.ab = ab.as<float>(); a.q = qv.as<float>();
+    a.stats = stats.as<float>(); a.rep_scratch = nullptr; a.ab = ab.as<float>(); a.q = qv.as<float>();
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_HIP_TRY(hipMemcpyAsync(q, qv.p, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));

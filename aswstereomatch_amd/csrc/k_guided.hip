@@ -83,6 +83,7 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         out_col[c] = (c0 + c < XO) && (xo0 + c0 + c < W);
     }
     const bool any_out = out_col[0];  // columns are adjacent: column 1 is an output only if column 0 is
+    if (!dst.active(kz[0], xo0, min(xo0 + XO, W) - 1)) return;  // consumers may skip whole slices / strips (wave-uniform)
     const int y0 = by * band, y1 = min(H, y0 + band);
     const double scale = 1.0 / ((double)k * (double)k);
     double vs[CPL][ND][NP];
@@ -199,9 +200,33 @@ struct GuideAccT {
 
 struct NoRaw {};
 
-// Guide statistics, interleaved per pixel: stats[kslot][y][x][SS] = {meanI_0..C-1, den_0..C-1, pad} with
-// SS = 8 (C=3) or 12 (C=6) floats, so the consumer fetches them with 2-3 dwordx4 loads.
-template <int C> struct StatStride { static constexpr int value = (C == 3) ? 8 : 12; };
+// Guide statistics, interleaved per pixel and per BGRX word: {meanI_0..2, den_0..2, pad, pad} = 8 floats, two dwordx4
+// loads for the consumer.  A 3-channel guide has one such array [slot][H][W][8]; a 6-channel guide has one per word plus,
+// when the guide is [fixed image, other image shifted by d] (GuidedF / GuidedF_3), a third one with the statistics of the
+// other image WITHOUT the shift:
+//   * the fixed word's statistics depend on the slice only through the normalisation scale, which is the same for whole
+//     groups of slices (rep[k] = first slice with the same scale/shift): computed for the representatives only;
+//   * away from the image border the box window of the shifted view holds exactly the pixels of the unshifted image at
+//     column x + sgn*d, so its statistics are read from the third array at that column; only the columns whose window
+//     touches the border or the reflected part of the view (d + r/2 columns on one side, r/2 on the other) are computed
+//     per slice.
+// GuidedF at 1080p D=128: two per-slice statistics passes of 5.9 ms each -> 0.3 + 0.3 + 1.0 ms.
+constexpr int SS8 = 8;
+struct StatsSplit {
+    float* half[2];    // [slot][H][W][8] per BGRX word, as the guide shows the word (shifted view included)
+    float* unshifted;  // [slot][H][W][8] of the shifted word's image without the shift, slot = group representative
+    const int* rep;    // group representative of every slice; null: no sharing (every slice has its own statistics)
+    int per_slice;     // 0: one slot (slice-independent guide)
+    int shifted;       // which word is shifted (0 / 1); -1: none
+    int sgn;           // the shifted word is read at x + sgn*d
+    int lo, hi;        // box window of output column x = [x - lo, x + hi]
+    int W, minD;
+    __device__ __forceinline__ bool interior(int x, int k) const
+    {
+        const int d = minD + k;
+        return sgn < 0 ? (x >= d + lo && x <= W - 1 - hi) : (x >= lo && x <= W - 1 - hi - d);
+    }
+};
 
 // box(I_c), box(I_c*I_c) -> meanI_c, den_c = (corrI_c - meanI_c^2) + eps      (M.cpp:2778, 2796-2799, 2846)
 template <int C, int W0, bool SHIFT>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
@@ -222,25 +247,51 @@ struct StatsSrc {
         for (int c = 0; c < 3; c++) { v[c] = I[3 * W0 + c]; v[3 + c] = I[3 * W0 + c] * I[3 * W0 + c]; }
     }
 };
-template <int C, int W0>
+// MODE 0: every slice; 1: group representatives only; 2: only the strips that contain border columns of the slice
+template <int MODE>
 struct StatsDst {
-    float* stats;
+    float* out;  // [slot][H][W][8]
+    StatsSplit sp;
     int H, W;
     float epsf;
     typedef NoRaw Raw;
+    __device__ __forceinline__ bool active(int k, int xa, int xb) const
+    {
+        if constexpr (MODE == 1) return sp.rep[k] == k;
+        if constexpr (MODE == 2) return !(sp.interior(xa, k) && sp.interior(xb, k));
+        return true;
+    }
     __device__ __forceinline__ Raw fetch(int, int, int) const { return Raw(); }
     __device__ __forceinline__ void emit(int y, int x, int k, const Raw&, const float (&m)[6]) const
     {
-        float* o = stats + (((size_t)k * H + y) * W + x) * StatStride<C>::value;
+        float* o = out + (((size_t)k * H + y) * W + x) * SS8;
+        float v[8];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float mm = m[c] * m[c];
             float var = m[3 + c] - mm;
-            o[3 * W0 + c] = m[c];
-            o[C + 3 * W0 + c] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
+            v[c] = m[c];
+            v[3 + c] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
         }
+        v[6] = 0.0f; v[7] = 0.0f;
+        reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
     }
 };
+
+// first slice with the same normalisation parameters (bitwise): the unshifted guide word looks the same in all of them
+__global__ void k_scale_groups(const float2* __restrict__ scales, int n, int* __restrict__ rep)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float2 me = scales[k];
+    int r = k;
+    for (int j = k - 1; j >= 0; j--) {
+        const float2 o = scales[j];
+        if (__float_as_uint(o.x) == __float_as_uint(me.x) && __float_as_uint(o.y) == __float_as_uint(me.y)) r = j;
+    }
+    rep[k] = r;
+}
 
 // a/b planes interleaved per pixel: ab[k][y][x][AS], AS = 4 (C=3) or 8 (C=6): {a_0..a_C-1, b, pad}
 template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
@@ -271,26 +322,44 @@ struct ABSrc {
         for (int c = 0; c < C; c++) v[1 + c] = I[c] * p;
     }
 };
-template <int C, bool PER_SLICE>  // PER_SLICE: the guide statistics depend on the slice (GuidedF)
+template <int C>
 struct ABDst {
-    const float* stats;
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
+    StatsSplit sp;
     float* ab;
     int H, W;
-    static constexpr int SS = StatStride<C>::value, AS = ABStride<C>::value;
-    struct Raw { float4 s[SS / 4]; };
+    static constexpr int AS = ABStride<C>::value;
+    struct Raw { float4 s[C == 3 ? 2 : 4]; };  // per word: {mean_0..2, den_0}, {den_1, den_2, -, -}
     __device__ __forceinline__ Raw fetch(int y, int x, int k) const
     {
         Raw r;
-        const float4* p = reinterpret_cast<const float4*>(stats + (((size_t)(PER_SLICE ? k : 0) * H + y) * W + x) * SS);
 #pragma unroll
-        for (int i = 0; i < SS / 4; i++) r.s[i] = p[i];
+        for (int w = 0; w < C / 3; w++) {
+            const float* base = sp.half[w];
+            int slot = sp.per_slice ? k : 0, xs = x;
+            if (sp.rep) {
+                if (w != sp.shifted) {
+                    slot = sp.rep[k];
+                } else if (sp.interior(x, k)) {
+                    base = sp.unshifted;
+                    slot = sp.rep[k];
+                    xs = x + sp.sgn * (sp.minD + k);
+                }
+            }
+            const float4* p = reinterpret_cast<const float4*>(base + (((size_t)slot * H + y) * W + xs) * SS8);
+            r.s[2 * w] = p[0];
+            r.s[2 * w + 1] = p[1];
+        }
         return r;
     }
     __device__ __forceinline__ void emit(int y, int x, int k, const Raw& r, const float (&m)[C + 1]) const
     {
-        float st[SS];
+        float mean[C], den[C];
 #pragma unroll
-        for (int i = 0; i < SS / 4; i++) { st[4 * i] = r.s[i].x; st[4 * i + 1] = r.s[i].y; st[4 * i + 2] = r.s[i].z; st[4 * i + 3] = r.s[i].w; }
+        for (int w = 0; w < C / 3; w++) {
+            mean[3 * w] = r.s[2 * w].x; mean[3 * w + 1] = r.s[2 * w].y; mean[3 * w + 2] = r.s[2 * w].z;
+            den[3 * w] = r.s[2 * w].w; den[3 * w + 1] = r.s[2 * w + 1].x; den[3 * w + 2] = r.s[2 * w + 1].y;
+        }
         const float meanP = m[0];
         float dot = 0.0f;
         float o[AS];
@@ -298,10 +367,10 @@ struct ABDst {
         for (int i = 0; i < AS; i++) o[i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            float mI = st[c];
+            float mI = mean[c];
             float mp = mI * meanP;
             float cov = m[1 + c] - mp;
-            float ac = cov / st[C + c];
+            float ac = cov / den[c];
             o[c] = ac;
             float pr = ac * mI;
             dot = (c == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
@@ -339,6 +408,7 @@ struct QSrc {
 };
 template <int C, bool SHIFT>
 struct QDst {
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
     GuideAccT<SHIFT> g;
     float* q;  // [n][H][W]
     int H, W;
@@ -393,6 +463,7 @@ struct U8Src {
     __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)r.v; }
 };
 struct PlaneDst {
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
     float* out;
     int H, W;
     typedef NoRaw Raw;
@@ -518,6 +589,7 @@ struct BloJSrc {  // slice z = ki * numD + i
 };
 
 struct BloJDst {
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
     BloKeys K;
     const float* bM;     // [nk][H][W]
     const uint8_t* ref;  // gray image of the reference view
@@ -592,17 +664,22 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     const int nstat = a.guide_per_slice ? a.n : 1;
     const float epsf = (float)a.eps;
     const bool shifted = a.shiftA != 0 || a.shiftB != 0 || a.guide_per_slice;
+    const size_t half_floats = (size_t)nstat * a.H * a.W * SS8;
+    StatsSplit sp;
+    sp.half[0] = a.stats; sp.half[1] = a.stats + half_floats; sp.unshifted = a.stats + 2 * half_floats;
+    sp.rep = nullptr; sp.per_slice = a.guide_per_slice ? 1 : 0; sp.shifted = -1; sp.sgn = 0;
+    sp.lo = a.r / 2; sp.hi = a.r - 1 - a.r / 2; sp.W = a.W; sp.minD = a.minD;
     int rc;
     if (a.C == 3 && !shifted) {
         // GuidedF_2 / 3-channel getGuidedFilter: the guide does not depend on the slice.
         // 1. guide statistics, once   2. a, b   3. q
         GuideAccT<false> g{a.guideA, a.guideB, a.gscales, 0, a.W, 0, 0, a.minD};
         StatsSrc<3, 0, false> ss{g};
-        StatsDst<3, 0> sd{a.stats, a.H, a.W, epsf};
+        StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
         rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, 1);
         if (rc != ASW_OK) return rc;
         ABSrc<3, false> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3, false> dst{a.stats, a.ab, a.H, a.W};
+        ABDst<3> dst{sp, a.ab, a.H, a.W};
         rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
@@ -612,34 +689,54 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     GuideAccT<true> g{a.guideA, a.guideB, a.gscales, a.guide_per_slice ? 1 : 0, a.W, a.shiftA, a.shiftB, a.minD};
     if (a.C == 3) {
         StatsSrc<3, 0, true> ss{g};
-        StatsDst<3, 0> sd{a.stats, a.H, a.W, epsf};
+        StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
         rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
         if (rc != ASW_OK) return rc;
         ABSrc<3, true> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3, true> dst{a.stats, a.ab, a.H, a.W};
+        ABDst<3> dst{sp, a.ab, a.H, a.W};
         rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
         QDst<3, true> qd{g, a.q, a.H, a.W};
         return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
     }
-    // 6-channel guide (GuidedF: statistics per slice; public getGuidedFilter: one slice)
+    // 6-channel guide
+    const bool share = a.guide_per_slice && a.rep_scratch && ((a.shiftA != 0) != (a.shiftB != 0));
     StatsSrc<6, 0, true> s0{g};
-    StatsDst<6, 0> d0{a.stats, a.H, a.W, epsf};
-    rc = launch_walk<6>(s, s0, d0, a.H, a.W, a.r, nstat);
-    if (rc != ASW_OK) return rc;
     StatsSrc<6, 1, true> s1{g};
-    StatsDst<6, 1> d1{a.stats, a.H, a.W, epsf};
-    rc = launch_walk<6>(s, s1, d1, a.H, a.W, a.r, nstat);
-    if (rc != ASW_OK) return rc;
-    ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
-    if (a.guide_per_slice) {
-        ABDst<6, true> dst{a.stats, a.ab, a.H, a.W};
-        rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
+    if (!share) {  // public getGuidedFilter (one slice) or both / no words shifted: plain per-slot statistics
+        StatsDst<0> d0{sp.half[0], sp, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, s0, d0, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
+        StatsDst<0> d1{sp.half[1], sp, a.H, a.W, epsf};
+        rc = launch_walk<6>(s, s1, d1, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
     } else {
-        ABDst<6, false> dst{a.stats, a.ab, a.H, a.W};
-        rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
+        // GuidedF / GuidedF_3: [fixed image, other image shifted by d].  See StatsSplit.
+        hipLaunchKernelGGL(k_scale_groups, dim3((a.n + 255) / 256), dim3(256), 0, s, a.gscales, a.n, a.rep_scratch);
+        sp.rep = a.rep_scratch;
+        sp.shifted = a.shiftA != 0 ? 0 : 1;
+        sp.sgn = a.shiftA != 0 ? a.shiftA : a.shiftB;
+        GuideAccT<true> gu = g;  // the same guide without the shift
+        gu.shiftA = 0; gu.shiftB = 0;
+        StatsSrc<6, 0, true> u0{gu};
+        StatsSrc<6, 1, true> u1{gu};
+        // fixed word: representatives only
+        StatsDst<1> df{sp.half[1 - sp.shifted], sp, a.H, a.W, epsf};
+        rc = sp.shifted == 1 ? launch_walk<6>(s, s0, df, a.H, a.W, a.r, a.n) : launch_walk<6>(s, s1, df, a.H, a.W, a.r, a.n);
+        if (rc != ASW_OK) return rc;
+        // shifted word's image without the shift: representatives only
+        StatsDst<1> du{sp.unshifted, sp, a.H, a.W, epsf};
+        rc = sp.shifted == 1 ? launch_walk<6>(s, u1, du, a.H, a.W, a.r, a.n) : launch_walk<6>(s, u0, du, a.H, a.W, a.r, a.n);
+        if (rc != ASW_OK) return rc;
+        // shifted word as the guide shows it: border strips of every slice
+        StatsDst<2> db{sp.half[sp.shifted], sp, a.H, a.W, epsf};
+        rc = sp.shifted == 1 ? launch_walk<6>(s, s1, db, a.H, a.W, a.r, a.n) : launch_walk<6>(s, s0, db, a.H, a.W, a.r, a.n);
+        if (rc != ASW_OK) return rc;
     }
+    ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
+    ABDst<6> dst{sp, a.ab, a.H, a.W};
+    rc = launch_walk<7>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
     QSrc<6> qs{a.ab, a.H, a.W};
     QDst<6, true> qd{g, a.q, a.H, a.W};
@@ -665,7 +762,8 @@ int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, in
     return ASW_OK;
 }
 
-size_t guided_stats_floats(int C, int nstat, int H, int W) { return (size_t)nstat * H * W * (C == 3 ? 8 : 12); }
+// one [slot][H][W][8] array for a 3-channel guide; three for a 6-channel guide (word A, word B, unshifted word: StatsSplit)
+size_t guided_stats_floats(int C, int nstat, int H, int W) { return (size_t)nstat * H * W * 8 * (C == 3 ? 1 : 3); }
 size_t guided_ab_floats(int C, int n, int H, int W) { return (size_t)n * H * W * (C == 3 ? 4 : 8); }
 
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, const int* keys, int nk, int step, int H,
