@@ -84,6 +84,18 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     }
     const bool any_out = out_col[0];  // columns are adjacent: column 1 is an output only if column 0 is
     if (!dst.active(kz[0], xo0, min(xo0 + XO, W) - 1)) return;  // consumers may skip whole slices / strips (wave-uniform)
+    // Everything a producer / consumer needs that depends only on (column, slice) -- reflected or shifted column indices,
+    // slice base pointers, normalisation parameters, key values -- is resolved ONCE here; the row walk adds the
+    // wave-uniform row offset only (the per-row index arithmetic used to be a third of the instructions of a step).
+    typename Src::Col scol[CPL][ND];
+    typename Dst::Col dcol[CPL][ND];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int n = 0; n < ND; n++) {
+            scol[c][n] = src.col(xin[c], kz[n]);
+            dcol[c][n] = dst.col(min(xo0 + c0 + c, W - 1), kz[n]);
+        }
     const int y0 = by * band, y1 = min(H, y0 + band);
     const double scale = 1.0 / ((double)k * (double)k);
     double vs[CPL][ND][NP];
@@ -106,9 +118,9 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         for (int c = 0; c < CPL; c++)
 #pragma unroll
             for (int n = 0; n < ND; n++) {
-                rn[c][n] = src.fetch(yn, xin[c], kz[n]);
-                if (s >= k) ro[c][n] = src.fetch(yo, xin[c], kz[n]);
-                if (s >= k - 1) rd[c][n] = dst.fetch(yd, min(xo0 + c0 + c, W - 1), kz[n]);
+                rn[c][n] = src.fetch(yn, scol[c][n]);
+                if (s >= k) ro[c][n] = src.fetch(yo, scol[c][n]);
+                if (s >= k - 1) rd[c][n] = dst.fetch(yd, dcol[c][n]);
             }
         // ---- vertical running sums (ColumnSum: SUM -= leaving row, SUM += entering row) ----
 #pragma unroll
@@ -117,12 +129,12 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             for (int n = 0; n < ND; n++) {
                 if (s >= k) {
                     float o[NP];
-                    src.eval(ro[c][n], kz[n], o);
+                    src.eval(ro[c][n], scol[c][n], o);
 #pragma unroll
                     for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] - (double)o[p];
                 }
                 float v[NP];
-                src.eval(rn[c][n], kz[n], v);
+                src.eval(rn[c][n], scol[c][n], v);
 #pragma unroll
                 for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] + (double)v[p];
             }
@@ -151,9 +163,9 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                         }
                     }
                     if (kvalid[n]) {
-                        dst.emit(y, xo0 + c0, kz[n], rd[0][n], m[0]);
+                        dst.emit(y, dcol[0][n], rd[0][n], m[0]);
                         if constexpr (CPL > 1) {
-                            if (out_col[CPL - 1]) dst.emit(y, xo0 + c0 + 1, kz[n], rd[CPL - 1][n], m[CPL - 1]);
+                            if (out_col[CPL - 1]) dst.emit(y, dcol[CPL - 1][n], rd[CPL - 1][n], m[CPL - 1]);
                         }
                     }
                 }
@@ -173,21 +185,32 @@ struct GuideAccT {
     const float2* scales;  // normalize() scale/shift per slice (index k * scale_stride)
     int scale_stride;
     int W, shiftA, shiftB, minD;
-    template <int NW>
-    __device__ __forceinline__ void fetch(int y, int x, int k, uint32_t (&u)[NW]) const
+    struct Col { const uint32_t* a; const uint32_t* b; float2 sc; };
+    __device__ __forceinline__ Col col(int x, int k) const
     {
+        Col c;
         if constexpr (SHIFT) {
-            u[0] = A[(size_t)y * W + (shiftA ? reflect_idx(x + shiftA * (minD + k), W) : x)];
-            if constexpr (NW > 1) u[1] = B[(size_t)y * W + (shiftB ? reflect_idx(x + shiftB * (minD + k), W) : x)];
-        } else {  // slice-independent: the same address for every k, so fetches of several slices merge
-            u[0] = A[(size_t)y * W + x];
-            if constexpr (NW > 1) u[1] = B[(size_t)y * W + x];
+            c.a = A + (shiftA ? reflect_idx(x + shiftA * (minD + k), W) : x);
+            c.b = B + (shiftB ? reflect_idx(x + shiftB * (minD + k), W) : x);  // never dereferenced when B is null (NW = 1)
+            c.sc = scales[k * scale_stride];
+        } else {  // slice-independent
+            c.a = A + x;
+            c.b = B + x;
+            c.sc = scales[0];
         }
+        return c;
     }
     template <int NW>
-    __device__ __forceinline__ void eval(const uint32_t (&u)[NW], int k, float (&I)[3 * NW]) const
+    __device__ __forceinline__ void fetch(int y, const Col& c, uint32_t (&u)[NW]) const
     {
-        const float2 sc = scales[SHIFT ? k * scale_stride : 0];
+        const size_t row = (size_t)y * W;
+        u[0] = c.a[row];
+        if constexpr (NW > 1) u[1] = c.b[row];
+    }
+    template <int NW>
+    __device__ __forceinline__ void eval(const uint32_t (&u)[NW], const Col& c, float (&I)[3 * NW]) const
+    {
+        const float2 sc = c.sc;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             // convertTo 8u->32f with float scale/shift (App. A-10): v_cvt_f32_ubyteN, mul, add
@@ -232,19 +255,21 @@ struct StatsSplit {
 template <int C, int W0, bool SHIFT>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
 struct StatsSrc {
     GuideAccT<SHIFT> g;
+    typedef typename GuideAccT<SHIFT>::Col Col;
     struct Raw { uint32_t u[C / 3]; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const { return g.col(x, k); }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
         Raw r;
-        g.template fetch<C / 3>(y, x, k, r.u);
+        g.template fetch<C / 3>(y, c, r.u);
         return r;
     }
-    __device__ __forceinline__ void eval(const Raw& r, int k, float (&v)[6]) const
+    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&v)[6]) const
     {
         float I[C];
-        g.template eval<C / 3>(r.u, k, I);
+        g.template eval<C / 3>(r.u, c, I);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { v[c] = I[3 * W0 + c]; v[3 + c] = I[3 * W0 + c] * I[3 * W0 + c]; }
+        for (int ch = 0; ch < 3; ch++) { v[ch] = I[3 * W0 + ch]; v[3 + ch] = I[3 * W0 + ch] * I[3 * W0 + ch]; }
     }
 };
 // MODE 0: every slice; 1: group representatives only; 2: only the strips that contain border columns of the slice
@@ -255,23 +280,25 @@ struct StatsDst {
     int H, W;
     float epsf;
     typedef NoRaw Raw;
+    struct Col { float* o; };
     __device__ __forceinline__ bool active(int k, int xa, int xb) const
     {
         if constexpr (MODE == 1) return sp.rep[k] == k;
         if constexpr (MODE == 2) return !(sp.interior(xa, k) && sp.interior(xb, k));
         return true;
     }
-    __device__ __forceinline__ Raw fetch(int, int, int) const { return Raw(); }
-    __device__ __forceinline__ void emit(int y, int x, int k, const Raw&, const float (&m)[6]) const
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{out + ((size_t)k * H * W + x) * SS8}; }
+    __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[6]) const
     {
-        float* o = out + (((size_t)k * H + y) * W + x) * SS8;
+        float* o = c.o + (size_t)y * W * SS8;
         float v[8];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float mm = m[c] * m[c];
-            float var = m[3 + c] - mm;
-            v[c] = m[c];
-            v[3 + c] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
+        for (int ch = 0; ch < 3; ch++) {
+            float mm = m[ch] * m[ch];
+            float var = m[3 + ch] - mm;
+            v[ch] = m[ch];
+            v[3 + ch] = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
         }
         v[6] = 0.0f; v[7] = 0.0f;
         reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -303,23 +330,24 @@ struct ABSrc {
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
     int H, W;
+    struct Col { typename GuideAccT<SHIFT>::Col g; const float* p; float2 sc; };
     struct Raw { uint32_t u[C / 3]; float p; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{g.col(x, k), P + (size_t)k * H * W + x, pscales[k]}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
         Raw r;
-        g.template fetch<C / 3>(y, x, k, r.u);
-        r.p = P[((size_t)k * H + y) * W + x];
+        g.template fetch<C / 3>(y, c.g, r.u);
+        r.p = c.p[(size_t)y * W];
         return r;
     }
-    __device__ __forceinline__ void eval(const Raw& r, int k, float (&v)[C + 1]) const
+    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&v)[C + 1]) const
     {
         float I[C];
-        g.template eval<C / 3>(r.u, k, I);
-        const float2 sc = pscales[k];
-        float p = r.p * sc.x + sc.y;
+        g.template eval<C / 3>(r.u, c.g, I);
+        float p = r.p * c.sc.x + c.sc.y;
         v[0] = p;
 #pragma unroll
-        for (int c = 0; c < C; c++) v[1 + c] = I[c] * p;
+        for (int ch = 0; ch < C; ch++) v[1 + ch] = I[ch] * p;
     }
 };
 template <int C>
@@ -329,10 +357,11 @@ struct ABDst {
     float* ab;
     int H, W;
     static constexpr int AS = ABStride<C>::value;
+    struct Col { const float* st[C / 3]; float* ab; };  // statistics of every word at this column (slot and shift resolved)
     struct Raw { float4 s[C == 3 ? 2 : 4]; };  // per word: {mean_0..2, den_0}, {den_1, den_2, -, -}
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const
     {
-        Raw r;
+        Col c;
 #pragma unroll
         for (int w = 0; w < C / 3; w++) {
             const float* base = sp.half[w];
@@ -346,13 +375,24 @@ struct ABDst {
                     xs = x + sp.sgn * (sp.minD + k);
                 }
             }
-            const float4* p = reinterpret_cast<const float4*>(base + (((size_t)slot * H + y) * W + xs) * SS8);
+            c.st[w] = base + ((size_t)slot * H * W + xs) * SS8;
+        }
+        c.ab = ab + ((size_t)k * H * W + x) * AS;
+        return c;
+    }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
+    {
+        Raw r;
+        const size_t row = (size_t)y * W * SS8;
+#pragma unroll
+        for (int w = 0; w < C / 3; w++) {
+            const float4* p = reinterpret_cast<const float4*>(c.st[w] + row);
             r.s[2 * w] = p[0];
             r.s[2 * w + 1] = p[1];
         }
         return r;
     }
-    __device__ __forceinline__ void emit(int y, int x, int k, const Raw& r, const float (&m)[C + 1]) const
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[C + 1]) const
     {
         float mean[C], den[C];
 #pragma unroll
@@ -366,17 +406,17 @@ struct ABDst {
 #pragma unroll
         for (int i = 0; i < AS; i++) o[i] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            float mI = mean[c];
+        for (int ch = 0; ch < C; ch++) {
+            float mI = mean[ch];
             float mp = mI * meanP;
-            float cov = m[1 + c] - mp;
-            float ac = cov / den[c];
-            o[c] = ac;
+            float cov = m[1 + ch] - mp;
+            float ac = cov / den[ch];
+            o[ch] = ac;
             float pr = ac * mI;
-            dot = (c == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
+            dot = (ch == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
         }
         o[C] = meanP - dot;
-        float4* dstp = reinterpret_cast<float4*>(ab + (((size_t)k * H + y) * W + x) * AS);
+        float4* dstp = reinterpret_cast<float4*>(c.ab + (size_t)y * W * AS);
 #pragma unroll
         for (int i = 0; i < AS / 4; i++) dstp[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
     }
@@ -388,22 +428,24 @@ struct QSrc {
     const float* ab;
     int H, W;
     static constexpr int AS = ABStride<C>::value;
+    struct Col { const float* ab; };
     struct Raw { float4 v[AS / 4]; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{ab + ((size_t)k * H * W + x) * AS}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
         Raw r;
-        const float4* p = reinterpret_cast<const float4*>(ab + (((size_t)k * H + y) * W + x) * AS);
+        const float4* p = reinterpret_cast<const float4*>(c.ab + (size_t)y * W * AS);
 #pragma unroll
         for (int i = 0; i < AS / 4; i++) r.v[i] = p[i];
         return r;
     }
-    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[C + 1]) const
+    __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[C + 1]) const
     {
         float t[AS];
 #pragma unroll
         for (int i = 0; i < AS / 4; i++) { t[4 * i] = r.v[i].x; t[4 * i + 1] = r.v[i].y; t[4 * i + 2] = r.v[i].z; t[4 * i + 3] = r.v[i].w; }
 #pragma unroll
-        for (int c = 0; c < C + 1; c++) v[c] = t[c];
+        for (int ch = 0; ch < C + 1; ch++) v[ch] = t[ch];
     }
 };
 template <int C, bool SHIFT>
@@ -412,24 +454,26 @@ struct QDst {
     GuideAccT<SHIFT> g;
     float* q;  // [n][H][W]
     int H, W;
+    struct Col { typename GuideAccT<SHIFT>::Col g; float* q; };
     struct Raw { uint32_t u[C / 3]; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{g.col(x, k), q + (size_t)k * H * W + x}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
         Raw r;
-        g.template fetch<C / 3>(y, x, k, r.u);
+        g.template fetch<C / 3>(y, c.g, r.u);
         return r;
     }
-    __device__ __forceinline__ void emit(int y, int x, int k, const Raw& r, const float (&m)[C + 1]) const
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[C + 1]) const
     {
         float I[C];
-        g.template eval<C / 3>(r.u, k, I);
+        g.template eval<C / 3>(r.u, c.g, I);
         float dot = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            float pr = m[c] * I[c];
-            dot = (c == 0) ? pr : dot + pr;
+        for (int ch = 0; ch < C; ch++) {
+            float pr = m[ch] * I[ch];
+            dot = (ch == 0) ? pr : dot + pr;
         }
-        q[((size_t)k * H + y) * W + x] = dot + m[C];
+        c.q[(size_t)y * W] = dot + m[C];
     }
 };
 
@@ -438,40 +482,40 @@ struct SadSrc {
     const uint8_t* gl;
     const uint8_t* gr;
     int W, minD, disp_type;
+    struct Col { const uint8_t* a; const uint8_t* b; };
     struct Raw { int a, b; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int k) const
+    __device__ __forceinline__ Col col(int x, int k) const
     {
         const int d = minD + k;
-        Raw r;
-        if (disp_type == ASW_DISPARITY_LEFT) {
-            r.a = gl[(size_t)y * W + x];
-            r.b = gr[(size_t)y * W + reflect_idx(x - d, W)];
-        } else {
-            r.a = gl[(size_t)y * W + reflect_idx(x + d, W)];
-            r.b = gr[(size_t)y * W + x];
-        }
-        return r;
+        if (disp_type == ASW_DISPARITY_LEFT) return Col{gl + x, gr + reflect_idx(x - d, W)};
+        return Col{gl + reflect_idx(x + d, W), gr + x};
     }
-    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)abs(r.a - r.b); }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
+    {
+        const size_t row = (size_t)y * W;
+        return Raw{(int)c.a[row], (int)c.b[row]};
+    }
+    __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[1]) const { v[0] = (float)abs(r.a - r.b); }
 };
 // plain 8U plane as f32 (boxFilter(8U -> CV_32F) of getInputImgNCC, M.cpp:785-786)
 struct U8Src {
     const uint8_t* img;
     int W;
+    struct Col { const uint8_t* p; };
     struct Raw { int v; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int) const { return Raw{(int)img[(size_t)y * W + x]}; }
-    __device__ __forceinline__ void eval(const Raw& r, int, float (&v)[1]) const { v[0] = (float)r.v; }
+    __device__ __forceinline__ Col col(int x, int) const { return Col{img + x}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const { return Raw{(int)c.p[(size_t)y * W]}; }
+    __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[1]) const { v[0] = (float)r.v; }
 };
 struct PlaneDst {
     __device__ __forceinline__ bool active(int, int, int) const { return true; }
     float* out;
     int H, W;
     typedef NoRaw Raw;
-    __device__ __forceinline__ Raw fetch(int, int, int) const { return Raw(); }
-    __device__ __forceinline__ void emit(int y, int x, int k, const Raw&, const float (&m)[1]) const
-    {
-        out[((size_t)k * H + y) * W + x] = m[0];
-    }
+    struct Col { float* o; };
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{out + (size_t)k * H * W + x}; }
+    __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[1]) const { c.o[(size_t)y * W] = m[0]; }
 };
 template <int NP, int CPL, int ND, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
@@ -537,32 +581,28 @@ struct BloView {  // |ref - k| and |other(shifted by the slice's disparity index
     const uint8_t* gl;
     const uint8_t* gr;
     int W, disp_type;
-    __device__ __forceinline__ void fetch(int y, int x, int i, int& a, int& b) const
+    struct Col { const uint8_t* a; const uint8_t* b; };
+    __device__ __forceinline__ Col col(int x, int i) const
     {
-        if (disp_type == ASW_DISPARITY_LEFT) {  // M.cpp:2566, 2573
-            a = gl[(size_t)y * W + x];
-            b = gr[(size_t)y * W + reflect_idx(x - i, W)];
-        } else {                                // M.cpp:2601, 2608
-            b = gr[(size_t)y * W + x];
-            a = gl[(size_t)y * W + reflect_idx(x + i, W)];
-        }
+        if (disp_type == ASW_DISPARITY_LEFT) return Col{gl + x, gr + reflect_idx(x - i, W)};  // M.cpp:2566, 2573
+        return Col{gl + reflect_idx(x + i, W), gr + x};                                        // M.cpp:2601, 2608
     }
 };
 
 struct BloMSrc {  // M of the last disparity index, one slice per key
     BloView v;
     BloKeys K;
+    struct Col { BloView::Col v; int key; };
     struct Raw { int a, b; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int ki) const
+    __device__ __forceinline__ Col col(int x, int ki) const { return Col{v.col(x, K.numD - 1), K.keys[ki]}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
-        Raw r;
-        v.fetch(y, x, K.numD - 1, r.a, r.b);
-        return r;
+        const size_t row = (size_t)y * v.W;
+        return Raw{(int)c.v.a[row], (int)c.v.b[row]};
     }
-    __device__ __forceinline__ void eval(const Raw& r, int ki, float (&o)[1]) const
+    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&o)[1]) const
     {
-        const int k = K.keys[ki];
-        o[0] = (float)abs(r.b - k) * (float)abs(r.a - k);
+        o[0] = (float)abs(r.b - c.key) * (float)abs(r.a - c.key);
     }
 };
 
@@ -571,20 +611,22 @@ struct BloJSrc {  // slice z = ki * numD + i
     BloKeys K;
     const float* cost;  // SAD cost volume [numD][H][W]
     int H;
+    struct Col { BloView::Col v; int key; const float* cost; };
     struct Raw { int a, b; float c; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int z) const
+    __device__ __forceinline__ Col col(int x, int z) const
     {
-        const int i = z % K.numD;
-        Raw r;
-        v.fetch(y, x, i, r.a, r.b);
-        r.c = cost[((size_t)i * H + y) * v.W + x];
-        return r;
+        const int ki = z / K.numD, i = z - ki * K.numD;
+        return Col{v.col(x, i), K.keys[ki], cost + (size_t)i * H * v.W + x};
     }
-    __device__ __forceinline__ void eval(const Raw& r, int z, float (&o)[1]) const
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
-        const int k = K.keys[z / K.numD];
-        float m = (float)abs(r.b - k) * (float)abs(r.a - k);  // M_k_y_r.mul(M_k_y_l)
-        o[0] = m * r.c;                                        // .mul(costs_ds[i]), M.cpp:2577
+        const size_t row = (size_t)y * v.W;
+        return Raw{(int)c.v.a[row], (int)c.v.b[row], c.cost[row]};
+    }
+    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&o)[1]) const
+    {
+        float m = (float)abs(r.b - c.key) * (float)abs(r.a - c.key);  // M_k_y_r.mul(M_k_y_l)
+        o[0] = m * r.c;                                                // .mul(costs_ds[i]), M.cpp:2577
     }
 };
 
@@ -596,25 +638,29 @@ struct BloJDst {
     float* lo;           // [numD][H][W]
     float* hi;
     int H, W;
+    struct Col { const float* bm; const uint8_t* ref; float* lo; float* hi; int ki, key; };
     struct Raw { float bm; int cur; };
-    __device__ __forceinline__ Raw fetch(int y, int x, int z) const
-    {
-        Raw r;
-        r.bm = bM[((size_t)(z / K.numD) * H + y) * W + x];
-        r.cur = ref[(size_t)y * W + x];
-        return r;
-    }
-    __device__ __forceinline__ void emit(int y, int x, int z, const Raw& r, const float (&m)[1]) const
+    __device__ __forceinline__ Col col(int x, int z) const
     {
         const int ki = z / K.numD, i = z - ki * K.numD;
+        const size_t o = (size_t)i * H * W + x;
+        return Col{bM + (size_t)ki * H * W + x, ref + x, lo + o, hi + o, ki, K.keys[ki]};
+    }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
+    {
+        const size_t row = (size_t)y * W;
+        return Raw{c.bm[row], (int)c.ref[row]};
+    }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[1]) const
+    {
         const float jb = m[0] / r.bm;  // setsJ_k_ds_y[i] / M_ki_kr_y, M.cpp:2588
-        const size_t o = ((size_t)i * H + y) * W + x;
+        const size_t row = (size_t)y * W;
         if (K.is_key(r.cur)) {  // setsJB_ks_ds_x.count(curIntensity) != 0, M.cpp:2663-2666
-            if (K.keys[ki] == r.cur) lo[o] = jb;
+            if (c.key == r.cur) c.lo[row] = jb;
             return;
         }
-        if (K.lower_index(r.cur) == ki) lo[o] = jb;
-        if (K.upper_index(r.cur) == ki) hi[o] = jb;
+        if (K.lower_index(r.cur) == c.ki) c.lo[row] = jb;
+        if (K.upper_index(r.cur) == c.ki) c.hi[row] = jb;
     }
 };
 
