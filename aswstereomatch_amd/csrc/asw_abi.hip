@@ -673,31 +673,19 @@ static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_vol
     if (step <= 0) return ASW_ERR_BAD_ARGUMENT;   // the reference's key loop would not terminate
     const int H = f->rows, W = f->cols, n = mp.numD;
     const size_t plane = (size_t)H * W;
-    std::vector<int> keys;
-    for (int i = 0; i < 256; i += step) keys.push_back(i);  // M.cpp:2551-2556
-    if (keys.back() != 255) keys.push_back(255);            // M.cpp:2557-2560
-    const int nk = (int)keys.size();
+    // keys 0, step, 2*step, ..., 255 (M.cpp:2551-2560) are implied by `step` in the kernel
     DevBuf& gl = ctx->buf("grayL");
     DevBuf& gr = ctx->buf("grayR");
     DevBuf& raw = ctx->buf("g_raw");
-    DevBuf& dk = ctx->buf("blo_keys");
-    DevBuf& bM = ctx->buf("blo_bM");
-    DevBuf& lo = ctx->buf("blo_lo");
-    DevBuf& hi = ctx->buf("blo_hi");
     ASW_TRY(gl.ensure(plane));
     ASW_TRY(gr.ensure(plane));
     ASW_TRY(raw.ensure(plane * n * 4));
-    ASW_TRY(dk.ensure((size_t)nk * sizeof(int)));
-    ASW_TRY(bM.ensure(plane * nk * 4));
-    ASW_TRY(lo.ensure(plane * n * 4));
-    ASW_TRY(hi.ensure(plane * n * 4));
     ASW_TRY(f->disp.ensure(plane * 4));
     f->vol_floats = 0;
     if (keep_volume) {
         ASW_TRY(f->vol.ensure(plane * n * 4));
         f->vol_floats = plane * n;
     }
-    ASW_HIP_TRY(hipMemcpyAsync(dk.p, keys.data(), (size_t)nk * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if (f->channels == 3) {  // M.cpp:2514-2521
         ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
         ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
@@ -708,12 +696,10 @@ static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_vol
     ASW_TRY(launch_cost_sad(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, n,
                             raw.as<float>()));  // M.cpp:2529-2547
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    ASW_TRY(launch_blo1(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), raw.as<float>(), dk.as<int>(), nk, step, H, W,
-                        mp.disparity_type, mp.win, n, bM.as<float>(), lo.as<float>(), hi.as<float>(),
+    ASW_TRY(launch_blo1(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), raw.as<float>(), step, H, W, mp.disparity_type, mp.win, n,
                         keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `keys` (host) must outlive the async copy
-    ctx->timing.aggregate_launches = 3;
+    ctx->timing.aggregate_launches = 1;
     return ASW_OK;
 }
 

@@ -161,8 +161,8 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
                    int max_off, float* out);
 
 // ---- O(1)-bilateral ASW (BLO1), k_guided.hip ----
-int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, const int* keys, int nk, int step, int H,
-                int W, int disp_type, int win, int numD, float* bM, float* lo, float* hi, float* vol, float* disp);
+int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,
+                int win, int numD, float* vol, float* disp);
 
 // ---- hooks for the batch scheduler (batch.hip) ----
 int asw_internal_stage_slot(asw_ctx* ctx, int slot, int rows, int cols, int channels, Frame** out);

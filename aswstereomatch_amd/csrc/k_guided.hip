@@ -557,137 +557,6 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// O(1)-bilateral ASW, computeAdaptiveWeight_BLO1 (M.cpp:2505-2725) -- SURVEY 8f row f1.
-// For every intensity key k and disparity index i the reference box-filters J = |R_i-k|*|L-k|*cost_i and divides
-// it by box(|R_last-k|*|L-k|) (the normaliser of the LAST disparity, M.cpp:2582); a pixel of intensity c then
-// blends the slices of the keys around c.  The 86 x D planes (91 GB at 1080p x D=128) are never stored: each
-// box-mean is routed straight to the (at most two) volumes a pixel reads -- `lo` (its own or lower key) and
-// `hi` (upper key) -- and k_blo1_wta blends and arg-mins them.
-// ---------------------------------------------------------------------------------------------------
-struct BloKeys {
-    const int* keys;   // key values, ascending
-    int nk, step, numD;
-    __device__ __forceinline__ bool is_key(int cur) const { return cur % step == 0 || cur == 255; }  // M.cpp:2551-2560
-    __device__ __forceinline__ int lower_index(int cur) const { return cur / step; }  // keys[cur/step] = cur/step*step
-    __device__ __forceinline__ int upper_index(int cur) const
-    {
-        int up = (cur / step) * step + step;  // M.cpp:2652-2657
-        return up > 255 ? nk - 1 : up / step;
-    }
-};
-
-struct BloView {  // |ref - k| and |other(shifted by the slice's disparity index) - k|
-    const uint8_t* gl;
-    const uint8_t* gr;
-    int W, disp_type;
-    struct Col { const uint8_t* a; const uint8_t* b; };
-    __device__ __forceinline__ Col col(int x, int i) const
-    {
-        if (disp_type == ASW_DISPARITY_LEFT) return Col{gl + x, gr + reflect_idx(x - i, W)};  // M.cpp:2566, 2573
-        return Col{gl + reflect_idx(x + i, W), gr + x};                                        // M.cpp:2601, 2608
-    }
-};
-
-struct BloMSrc {  // M of the last disparity index, one slice per key
-    BloView v;
-    BloKeys K;
-    struct Col { BloView::Col v; int key; };
-    struct Raw { int a, b; };
-    __device__ __forceinline__ Col col(int x, int ki) const { return Col{v.col(x, K.numD - 1), K.keys[ki]}; }
-    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
-    {
-        const size_t row = (size_t)y * v.W;
-        return Raw{(int)c.v.a[row], (int)c.v.b[row]};
-    }
-    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&o)[1]) const
-    {
-        o[0] = (float)abs(r.b - c.key) * (float)abs(r.a - c.key);
-    }
-};
-
-struct BloJSrc {  // slice z = ki * numD + i
-    BloView v;
-    BloKeys K;
-    const float* cost;  // SAD cost volume [numD][H][W]
-    int H;
-    struct Col { BloView::Col v; int key; const float* cost; };
-    struct Raw { int a, b; float c; };
-    __device__ __forceinline__ Col col(int x, int z) const
-    {
-        const int ki = z / K.numD, i = z - ki * K.numD;
-        return Col{v.col(x, i), K.keys[ki], cost + (size_t)i * H * v.W + x};
-    }
-    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
-    {
-        const size_t row = (size_t)y * v.W;
-        return Raw{(int)c.v.a[row], (int)c.v.b[row], c.cost[row]};
-    }
-    __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&o)[1]) const
-    {
-        float m = (float)abs(r.b - c.key) * (float)abs(r.a - c.key);  // M_k_y_r.mul(M_k_y_l)
-        o[0] = m * r.c;                                                // .mul(costs_ds[i]), M.cpp:2577
-    }
-};
-
-struct BloJDst {
-    __device__ __forceinline__ bool active(int, int, int) const { return true; }
-    BloKeys K;
-    const float* bM;     // [nk][H][W]
-    const uint8_t* ref;  // gray image of the reference view
-    float* lo;           // [numD][H][W]
-    float* hi;
-    int H, W;
-    struct Col { const float* bm; const uint8_t* ref; float* lo; float* hi; int ki, key; };
-    struct Raw { float bm; int cur; };
-    __device__ __forceinline__ Col col(int x, int z) const
-    {
-        const int ki = z / K.numD, i = z - ki * K.numD;
-        const size_t o = (size_t)i * H * W + x;
-        return Col{bM + (size_t)ki * H * W + x, ref + x, lo + o, hi + o, ki, K.keys[ki]};
-    }
-    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
-    {
-        const size_t row = (size_t)y * W;
-        return Raw{c.bm[row], (int)c.ref[row]};
-    }
-    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[1]) const
-    {
-        const float jb = m[0] / r.bm;  // setsJ_k_ds_y[i] / M_ki_kr_y, M.cpp:2588
-        const size_t row = (size_t)y * W;
-        if (K.is_key(r.cur)) {  // setsJB_ks_ds_x.count(curIntensity) != 0, M.cpp:2663-2666
-            if (c.key == r.cur) c.lo[row] = jb;
-            return;
-        }
-        if (K.lower_index(r.cur) == c.ki) c.lo[row] = jb;
-        if (K.upper_index(r.cur) == c.ki) c.hi[row] = jb;
-    }
-};
-
-__global__ __launch_bounds__(256) void k_blo1_wta(BloKeys K, const uint8_t* __restrict__ ref, const float* __restrict__ lo,
-                                                  const float* __restrict__ hi, size_t plane, float* __restrict__ vol,
-                                                  float* __restrict__ disp)
-{
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= plane) return;
-    const int cur = ref[p];
-    const int li = K.lower_index(cur);
-    const bool exact = K.is_key(cur);
-    int lower = K.keys[li], upper = lower + K.step;
-    if (upper > 255) upper = 255;
-    const float wl = (float)(cur - lower), wu = (float)(upper - cur);
-    double best = 1.7976931348623157e308;
-    float bd = 0.0f;
-    for (int i = 0; i < K.numD; i++) {
-        float c;
-        if (exact) c = lo[(size_t)i * plane + p];
-        else c = wl * lo[(size_t)i * plane + p] + wu * hi[(size_t)i * plane + p];  // M.cpp:2659-2660 (weights as written)
-        if (vol) vol[(size_t)i * plane + p] = c;
-        if ((double)c < best) { best = (double)c; bd = (float)i; }  // minDisparity == 0 only (see run_blo1)
-    }
-    disp[p] = bd;
-}
-
 }  // namespace
 
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
@@ -812,28 +681,3 @@ int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, in
 // one [slot][H][W][8] array for a 3-channel guide; three for a 6-channel guide (word A, word B, unshifted word: StatsSplit)
 size_t guided_stats_floats(int C, int nstat, int H, int W) { return (size_t)nstat * H * W * 8 * (C == 3 ? 1 : 3); }
 size_t guided_ab_floats(int C, int n, int H, int W) { return (size_t)n * H * W * (C == 3 ? 4 : 8); }
-
-int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, const int* keys, int nk, int step, int H,
-                int W, int disp_type, int win, int numD, float* bM, float* lo, float* hi, float* vol, float* disp)
-{
-    BloKeys K{keys, nk, step, numD};
-    BloView v{gl, gr, W, disp_type};
-    int rc;
-    {
-        BloMSrc src{v, K};
-        PlaneDst dst{bM, H, W};
-        rc = launch_walk<1>(s, src, dst, H, W, win, nk);
-        if (rc != ASW_OK) return rc;
-    }
-    {
-        BloJSrc src{v, K, cost, H};
-        BloJDst dst{K, bM, disp_type == ASW_DISPARITY_LEFT ? gl : gr, lo, hi, H, W};
-        rc = launch_walk<1>(s, src, dst, H, W, win, nk * numD);
-        if (rc != ASW_OK) return rc;
-    }
-    const size_t plane = (size_t)H * W;
-    hipLaunchKernelGGL(k_blo1_wta, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, K,
-                       disp_type == ASW_DISPARITY_LEFT ? gl : gr, lo, hi, plane, vol, disp);
-    ASW_HIP_TRY(hipGetLastError());
-    return ASW_OK;
-}
