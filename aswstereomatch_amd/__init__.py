@@ -308,6 +308,33 @@ class Context:
         self._finish(self._lib.asw_download_volume(self._h, slot, vol.ctypes.data_as(C.c_void_p), vol.size), "asw_download_volume")
         return vol
 
+    # ---- driver-side pre/post-processing on the device (aswStereoMatch.cpp:30-31, 67-89, 97-98) ----
+    def preprocess_pair(self, slot, left_full, right_full, dsize=(640, 360), detail_boost=True):
+        """resize(img, Size(w, h)) + the HSV-V bilateral detail boost of the reference's main(); the result becomes the
+        resident pair of `slot`."""
+        li, la = _image(left_full)
+        ri, ra = _image(right_full)
+        rc = self._lib.asw_preprocess_pair(self._h, slot, C.byref(li), C.byref(ri), int(dsize[0]), int(dsize[1]),
+                                           1 if detail_boost else 0)
+        return self._finish(rc, "asw_preprocess_pair")
+
+    def download_pair(self, slot, shape):
+        """The resident 8U pair of `slot` (e.g. after preprocess_pair); shape = (rows, cols, channels)."""
+        left = np.zeros(shape, np.uint8)
+        right = np.zeros(shape, np.uint8)
+        li, _ = _image(left)
+        ri, _ = _image(right)
+        self._finish(self._lib.asw_download_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_download_pair")
+        return left, right
+
+    def download_disparity_u8(self, slot, shape, normalize=True):
+        """disparityMap.convertTo(CV_8UC1) [+ normalize(0, 255, NORM_MINMAX)] of the last match of `slot` (main.cpp:97-98)."""
+        out = np.zeros(shape, np.uint8)
+        oi, _ = _image(out)
+        self._finish(self._lib.asw_download_disparity_u8(self._h, slot, C.byref(oi), 1 if normalize else 0),
+                     "asw_download_disparity_u8")
+        return out
+
     def timing(self):
         t = AswTiming()
         self._lib.asw_get_timing(self._h, C.byref(t))

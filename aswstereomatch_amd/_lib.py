@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "asw_aggregate_bilateral", "asw_aggregate_geodesic", "asw_aggregate_guided", "asw_aggregate_guided2",
     "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_direct8", "asw_aggregate_guided3",
     "asw_cost_ncc", "asw_ncc_disparity",
+    "asw_preprocess_pair", "asw_download_pair", "asw_download_disparity_u8",
     "asw_cost_ad", "asw_cost_tad", "asw_cost_similarity", "asw_cost_sad",
     "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray",
     "asw_stereo_match_batch",
@@ -78,6 +79,9 @@ def lib():
         l.asw_aggregate_guided3.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_cost_ncc.argtypes = [P, IMG, IMG, P, I, I, I, I, I]
         l.asw_ncc_disparity.argtypes = [P, IMG, IMG, IMG, I, I, I, I]
+        l.asw_preprocess_pair.argtypes = [P, I, IMG, IMG, I, I, I]
+        l.asw_download_pair.argtypes = [P, I, IMG, IMG]
+        l.asw_download_disparity_u8.argtypes = [P, I, IMG, I]
         l.asw_aggregate_guided.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_aggregate_guided2.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P]

@@ -51,6 +51,7 @@ struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
 
 struct asw_ctx {
     int device = 0;
+    int prep_ntaps = 0;  // taps of the pre-processing bilateral filter (tables in buf("prep_tables"))
     hipStream_t stream = nullptr;
     std::vector<Frame> frames;
     std::map<std::string, DevBuf> scratch;  // named grow-only scratch buffers
@@ -122,6 +123,13 @@ int launch_box_mean_u8(hipStream_t s, const uint8_t* img, int H, int W, int win,
 int launch_ncc_selfsum(hipStream_t s, const uint8_t* g, const float* mean, int H, int W, int win, double* ss);
 int launch_ncc(hipStream_t s, const NccLaunch& a);
 int launch_apply_scales(hipStream_t s, float* vol, int n, size_t plane, const float2* scales);
+
+// ---- driver-side pre/post-processing (k_prep.hip), SURVEY 8f row f3 ----
+int launch_resize_linear(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+int launch_bgr2hsv(hipStream_t s, const uint8_t* bgr, size_t n, const int* sdiv, const int* hdiv, uint8_t* hsv);
+int launch_boost_hsv2bgr(hipStream_t s, const uint8_t* hsv, int H, int W, const int* taps, int ntaps, const float* color_lut,
+                         uint8_t* bgr);
+int launch_disp_to_u8(hipStream_t s, const float* disp, size_t n, int normalize, uint8_t* out, int* mm_scratch);
 
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost);

@@ -106,6 +106,17 @@ int asw_download_volume(asw_ctx* ctx, int slot, float* cost_volume_out, size_t n
 int asw_synchronize(asw_ctx* ctx);
 int asw_get_timing(asw_ctx* ctx, asw_timing* out);
 
+/* ---- driver-side pre/post-processing on the device (aswStereoMatch.cpp, "main.cpp") ----
+ * asw_preprocess_pair: main.cpp:30-31 resize(img, Size(out_width, out_height)) (INTER_LINEAR) and, if detail_boost != 0,
+ * main.cpp:67-89 (BGR2HSV, V += 2*(V - bilateralFilter(V, 7, 10, 3, BORDER_REFLECT)), HSV2BGR) for both 8UC3 images; the
+ * result becomes the resident pair of `slot` (as after asw_upload_pair).  asw_download_pair fetches it.
+ * asw_download_disparity_u8: main.cpp:97-98 disparityMap.convertTo(CV_8UC1) and, if normalize != 0,
+ * normalize(.., 0, 255, NORM_MINMAX) of the last asw_match_resident result of `slot`; disp_u8: ASW_8U, 1 channel. */
+int asw_preprocess_pair(asw_ctx* ctx, int slot, const asw_image* left_full, const asw_image* right_full, int out_width,
+                        int out_height, int detail_boost);
+int asw_download_pair(asw_ctx* ctx, int slot, asw_image* left, asw_image* right);
+int asw_download_disparity_u8(asw_ctx* ctx, int slot, asw_image* disp_u8, int normalize);
+
 /* ---- per-method entry points with explicit parameters (M.h:133-184) ---- */
 /* computeAdaptiveWeight, M.h:133-134, M.cpp:1016-1156 */
 int asw_aggregate_bilateral(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,

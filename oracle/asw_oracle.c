@@ -1307,6 +1307,225 @@ int orc_asw_direct8(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int 
 }
 
 /* ---------------------------------------------------------------------------------------
+ * Driver-side pre/post-processing, aswStereoMatch.cpp ("main.cpp") :30-31, 67-89, 97-98.
+ * Five more OpenCV 4.1.0 primitives, restated from their portable C++ paths; none can be verified offline (no OpenCV,
+ * no fixture): resize(INTER_LINEAR) on 8UC3 with 11-bit fixed-point coefficients (and its silent switch to INTER_AREA for
+ * an exact 2x downscale), cvtColor BGR2HSV / HSV2BGR on 8U (H in [0,180)), bilateralFilter on 8UC1 (f32 accumulation in
+ * tap order, BORDER_REFLECT), saturating u8 MatExpr arithmetic, convertTo(CV_8U) + normalize(0,255,NORM_MINMAX).
+ * Builds with IPP (the reference's Windows OpenCV) may take other code paths for resize and bilateralFilter.
+ * ------------------------------------------------------------------------------------- */
+static inline int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+static inline int cv_round_f(float v) { return (int)lrintf(v); }   /* cvRound: to nearest, ties to even */
+static inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+
+/* resize(src, dst, Size(dw, dh)) with the default INTER_LINEAR, main.cpp:30-31 */
+void orc_resize_linear_u8c3(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw)
+{
+    const int cn = 3;
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+    /* cv::resize: INTER_LINEAR with an exact 2x2 integer downscale is executed as INTER_AREA (fast 2x2 average) */
+    {
+        int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y); /* saturate_cast<int>(scale) */
+        int fast = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON;
+        if (fast && isx == 2 && isy == 2) {
+            for (int y = 0; y < dh; y++)
+                for (int x = 0; x < dw; x++)
+                    for (int c = 0; c < cn; c++) {
+                        const uint8_t* p = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+                        dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((p[0] + p[cn] + p[(size_t)sw * cn] + p[(size_t)sw * cn + cn] + 2) >> 2);
+                    }
+            return;
+        }
+    }
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    short* ialpha = (short*)malloc(sizeof(short) * dw * 2);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) { if (dx < xmax) xmax = dx; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+        xofs[dx] = sx;
+        int a0 = cv_round_f((1.f - fx) * 2048.f), a1 = cv_round_f(fx * 2048.f);
+        ialpha[dx * 2] = (short)a0; ialpha[dx * 2 + 1] = (short)a1;
+    }
+    int* rows = (int*)malloc(sizeof(int) * (size_t)dw * cn * 2);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        /* no reset of fy at the borders in y: resizeGeneric_ clips the two source ROWS to the image instead */
+        int b0 = cv_round_f((1.f - fy) * 2048.f), b1 = cv_round_f(fy * 2048.f);
+        for (int k = 0; k < 2; k++) {
+            int yy = sy + k; if (yy < 0) yy = 0; if (yy > sh - 1) yy = sh - 1;
+            const uint8_t* S = src + (size_t)yy * sw * cn;
+            int* D = rows + (size_t)k * dw * cn;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int sx = xofs[dx] * cn + c;
+                    D[dx * cn + c] = dx < xmax ? S[sx] * ialpha[dx * 2] + S[sx + cn] * ialpha[dx * 2 + 1] : S[sx] * 2048;
+                }
+        }
+        const int *S0 = rows, *S1 = rows + (size_t)dw * cn;
+        for (int x = 0; x < dw * cn; x++) /* VResizeLinear<uchar,int,short,...>: the truncating 8u form */
+            dst[(size_t)dy * dw * cn + x] = (uint8_t)((((b0 * (S0[x] >> 4)) >> 16) + ((b1 * (S1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(ialpha); free(rows);
+}
+
+/* cvtColor(COLOR_BGR2HSV) on 8U, main.cpp:70-71: V = max, S = diff*255/V, H = 30*sector arithmetic, 12-bit tables */
+void orc_bgr2hsv_u8(const uint8_t* bgr, size_t n, uint8_t* hsv)
+{
+    const int hsv_shift = 12;
+    static int sdiv[256], hdiv[256], init = 0;
+    if (!init) {
+        sdiv[0] = hdiv[0] = 0;
+        for (int i = 1; i < 256; i++) {
+            sdiv[i] = (int)lrint((255 << hsv_shift) / (1. * i));
+            hdiv[i] = (int)lrint((180 << hsv_shift) / (6. * i));
+        }
+        init = 1;
+    }
+    for (size_t i = 0; i < n; i++) {
+        int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        int v = b, vmin = b;
+        if (g > v) v = g;
+        if (r > v) v = r;
+        if (g < vmin) vmin = g;
+        if (r < vmin) vmin = r;
+        int diff = v - vmin;
+        int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+        int s = (diff * sdiv[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+        h = (h * hdiv[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        h += h < 0 ? 180 : 0;
+        hsv[3 * i] = (uint8_t)sat_u8(h); hsv[3 * i + 1] = (uint8_t)s; hsv[3 * i + 2] = (uint8_t)v;
+    }
+}
+
+/* cvtColor(COLOR_HSV2BGR) on 8U, main.cpp:80,88: through f32 (HSV2RGB_f), *255, cvRound */
+void orc_hsv2bgr_u8(const uint8_t* hsv, size_t n, uint8_t* bgr)
+{
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    const float hscale = 6.f / 180.f;
+    for (size_t i = 0; i < n; i++) {
+        float h = (float)hsv[3 * i], s = hsv[3 * i + 1] * (1.f / 255.f), v = hsv[3 * i + 2] * (1.f / 255.f);
+        float b, g, r;
+        if (s == 0) b = g = r = v;
+        else {
+            float tab[4];
+            h *= hscale;
+            if (h < 0) do h += 6; while (h < 0);
+            else if (h >= 6) do h -= 6; while (h >= 6);
+            int sector = cv_floor_f(h);
+            h -= sector;
+            if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+            tab[0] = v;
+            tab[1] = v * (1.f - s);
+            tab[2] = v * (1.f - s * h);
+            tab[3] = v * (1.f - s * (1.f - h));
+            b = tab[sector_data[sector][0]]; g = tab[sector_data[sector][1]]; r = tab[sector_data[sector][2]];
+        }
+        bgr[3 * i] = (uint8_t)sat_u8(cv_round_f(b * 255.f));
+        bgr[3 * i + 1] = (uint8_t)sat_u8(cv_round_f(g * 255.f));
+        bgr[3 * i + 2] = (uint8_t)sat_u8(cv_round_f(r * 255.f));
+    }
+}
+
+/* taps of bilateralFilter(d, sigmaColor, sigmaSpace): circular support, raster order; returns the number of taps */
+int orc_bilateral_taps(int d, double sigma_space, int* dy, int* dx, float* w)
+{
+    if (sigma_space <= 0) sigma_space = 1;
+    int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    const double gs = -0.5 / (sigma_space * sigma_space);
+    int n = 0;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            dy[n] = i; dx[n] = j; w[n] = (float)exp(r * r * gs);
+            n++;
+        }
+    return n;
+}
+void orc_bilateral_color_lut(double sigma_color, float* lut /* 256 */)
+{
+    if (sigma_color <= 0) sigma_color = 1;
+    const double gc = -0.5 / (sigma_color * sigma_color);
+    for (int i = 0; i < 256; i++) lut[i] = (float)exp((double)i * i * gc);
+}
+
+/* bilateralFilter(src 8UC1, dst, d, sigmaColor, sigmaSpace, BORDER_REFLECT), main.cpp:76,84 */
+void orc_bilateral_u8c1(const uint8_t* src, int H, int W, int d, double sigma_color, double sigma_space, uint8_t* dst)
+{
+    int dy[1024], dx[1024];
+    float sw[1024], cw[256];
+    const int nt = orc_bilateral_taps(d, sigma_space, dy, dx, sw);
+    orc_bilateral_color_lut(sigma_color, cw);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float sum = 0, wsum = 0;
+            const int val0 = src[(size_t)y * W + x];
+            for (int k = 0; k < nt; k++) {
+                const int val = src[(size_t)reflect_idx(y + dy[k], H) * W + reflect_idx(x + dx[k], W)];
+                const float w = sw[k] * cw[val > val0 ? val - val0 : val0 - val];
+                sum += val * w;
+                wsum += w;
+            }
+            dst[(size_t)y * W + x] = (uint8_t)cv_round_f(sum / wsum);
+        }
+}
+
+/* the HSV-V detail boost of main.cpp:67-89 on one BGR image: V += 2 * (V - bilateral(V, 7, 10, 3)) with u8 saturation */
+void orc_detail_boost(const uint8_t* bgr, int H, int W, uint8_t* out)
+{
+    const size_t N = (size_t)H * W;
+    uint8_t* hsv = (uint8_t*)malloc(N * 3);
+    uint8_t* v = (uint8_t*)malloc(N);
+    uint8_t* blur = (uint8_t*)malloc(N);
+    orc_bgr2hsv_u8(bgr, N, hsv);
+    for (size_t i = 0; i < N; i++) v[i] = hsv[3 * i + 2];
+    orc_bilateral_u8c1(v, H, W, 7, 10, 3, blur);
+    for (size_t i = 0; i < N; i++) {
+        int detail = sat_u8(v[i] - blur[i]);                 /* mat3cn[2] - blurL */
+        hsv[3 * i + 2] = (uint8_t)sat_u8(v[i] + 2 * detail); /* mat3cn[2] + detailL * 2 (addWeighted: exact integers) */
+    }
+    orc_hsv2bgr_u8(hsv, N, out);
+    free(hsv); free(v); free(blur);
+}
+
+/* main.cpp:30-31 + 67-89 for one image */
+void orc_preprocess(const uint8_t* src, int sh, int sw, int dh, int dw, int boost, uint8_t* out)
+{
+    uint8_t* small = (uint8_t*)malloc((size_t)dh * dw * 3);
+    orc_resize_linear_u8c3(src, sh, sw, small, dh, dw);
+    if (boost) orc_detail_boost(small, dh, dw, out);
+    else memcpy(out, small, (size_t)dh * dw * 3);
+    free(small);
+}
+
+/* main.cpp:97-98: convertTo(CV_8UC1), then (normalize != 0) normalize(0, 255, NORM_MINMAX) */
+void orc_disparity_to_u8(const float* disp, size_t n, int normalize, uint8_t* out)
+{
+    int mn = 255, mx = 0;
+    for (size_t i = 0; i < n; i++) {
+        int v = sat_u8(cv_round_f(disp[i]));
+        out[i] = (uint8_t)v;
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    if (!normalize) return;
+    double scale = 255.0 * ((double)(mx - mn) > DBL_EPSILON ? 1.0 / (double)(mx - mn) : 0.0);
+    double shift = 0.0 - (double)mn * scale;
+    const float fs = (float)scale, fb = (float)shift;
+    for (size_t i = 0; i < n; i++) out[i] = (uint8_t)sat_u8(cv_round_f(out[i] * fs + fb));
+}
+
+/* ---------------------------------------------------------------------------------------
  * stereoMatching selector, M.cpp:46-88, with the literals it hard-codes.
  * ------------------------------------------------------------------------------------- */
 int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int disparity_type, int algorithm, int win,

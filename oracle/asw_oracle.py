@@ -270,3 +270,67 @@ def stereo_matching(L, R, disparity_type, algorithm, win=15, minD=0, numD=64):
     disp, pd = _out((H, W), np.float32)
     rc = lib().orc_stereo_matching(L.ctypes.data_as(C.c_void_p), pr, H, W, disparity_type, algorithm, win, minD, numD, pd)
     return rc, disp
+
+
+# ---- driver-side pre/post-processing ----
+def resize_linear(img, dsize):
+    """cv::resize(img, Size(w, h)) with INTER_LINEAR on 8UC3; dsize = (w, h)."""
+    img, p = _u8(img)
+    sh, sw, _ = img.shape
+    dw, dh = dsize
+    out, po = _out((dh, dw, 3), np.uint8)
+    lib().orc_resize_linear_u8c3(p, sh, sw, po, dh, dw)
+    return out
+
+
+def bgr2hsv(img):
+    img, p = _u8(img)
+    out, po = _out(img.shape, np.uint8)
+    lib().orc_bgr2hsv_u8(p, C.c_size_t(img.shape[0] * img.shape[1]), po)
+    return out
+
+
+def hsv2bgr(img):
+    img, p = _u8(img)
+    out, po = _out(img.shape, np.uint8)
+    lib().orc_hsv2bgr_u8(p, C.c_size_t(img.shape[0] * img.shape[1]), po)
+    return out
+
+
+def bilateral_u8(plane, d=7, sigma_color=10.0, sigma_space=3.0):
+    plane, p = _u8(plane)
+    out, po = _out(plane.shape, np.uint8)
+    lib().orc_bilateral_u8c1(p, plane.shape[0], plane.shape[1], d, C.c_double(sigma_color), C.c_double(sigma_space), po)
+    return out
+
+
+def bilateral_tables(d=7, sigma_color=10.0, sigma_space=3.0):
+    dy = np.zeros(1024, np.int32); dx = np.zeros(1024, np.int32); w = np.zeros(1024, np.float32)
+    n = lib().orc_bilateral_taps(d, C.c_double(sigma_space), dy.ctypes.data_as(C.c_void_p), dx.ctypes.data_as(C.c_void_p),
+                                 w.ctypes.data_as(C.c_void_p))
+    lut = np.zeros(256, np.float32)
+    lib().orc_bilateral_color_lut(C.c_double(sigma_color), lut.ctypes.data_as(C.c_void_p))
+    return dy[:n].copy(), dx[:n].copy(), w[:n].copy(), lut
+
+
+def detail_boost(img):
+    img, p = _u8(img)
+    out, po = _out(img.shape, np.uint8)
+    lib().orc_detail_boost(p, img.shape[0], img.shape[1], po)
+    return out
+
+
+def preprocess(img, dsize, boost=True):
+    img, p = _u8(img)
+    sh, sw, _ = img.shape
+    dw, dh = dsize
+    out, po = _out((dh, dw, 3), np.uint8)
+    lib().orc_preprocess(p, sh, sw, dh, dw, int(bool(boost)), po)
+    return out
+
+
+def disparity_to_u8(disp, normalize=True):
+    disp, p = _f32(disp)
+    out, po = _out(disp.shape, np.uint8)
+    lib().orc_disparity_to_u8(p, C.c_size_t(disp.size), int(bool(normalize)), po)
+    return out

@@ -30,6 +30,8 @@ def main():
     out["similarity"] = O.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1]
     out["sad"] = O.cost_sad(L, R, 0, WIN, 0, D)[1]
     out["geodesic_dist_L"] = O.geodesic_dist(L, WIN, 3)[1]
+    out["prep_L"] = O.preprocess(L, (40, 26), True)            # row f3: resize + HSV-V bilateral detail boost
+    out["prep_R_noboost"] = O.preprocess(R, (24, 16), False)
     out["ncc_raw"] = O.cost_ncc(L, R, 0, WIN, 0, D, raw=True)[1]
     out["ncc"] = O.cost_ncc(L, R, 0, WIN, 0, D)[1]
     out["ncc_disp"] = O.ncc_disparity(L, R, 0, WIN, 0, D)[1]
@@ -49,6 +51,7 @@ def main():
         assert rc == 0
         out[name + "_disp"] = disp
         out[name + "_vol"] = vol
+    out["classic_disp_u8"] = O.disparity_to_u8(out["classic_disp"], True)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "asw_golden_v1.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

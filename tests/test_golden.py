@@ -22,6 +22,9 @@ def test_oracle_reproduces_golden(oracle, gold):
     assert np.array_equal(oracle.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1], gold["similarity"])
     assert np.array_equal(oracle.cost_sad(L, R, 0, WIN, 0, D)[1], gold["sad"])
     assert np.array_equal(oracle.geodesic_dist(L, WIN, 3)[1], gold["geodesic_dist_L"])
+    assert np.array_equal(oracle.preprocess(L, (40, 26), True), gold["prep_L"])
+    assert np.array_equal(oracle.preprocess(R, (24, 16), False), gold["prep_R_noboost"])
+    assert np.array_equal(oracle.disparity_to_u8(gold["classic_disp"], True), gold["classic_disp_u8"])
     assert np.array_equal(oracle.cost_ncc(L, R, 0, WIN, 0, D, raw=True)[1], gold["ncc_raw"])
     assert np.array_equal(oracle.cost_ncc(L, R, 0, WIN, 0, D)[1], gold["ncc"])
     assert np.array_equal(oracle.ncc_disparity(L, R, 0, WIN, 0, D)[1], gold["ncc_disp"])
@@ -64,6 +67,13 @@ def test_hip_reproduces_golden(gold):
     assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, D)), gold["similarity"])
     assert np.array_equal(np.stack(ctx.getCostSAD(L, R, LEFT, WIN, 0, D)), gold["sad"])
     assert np.array_equal(ctx.getGeodesicDist(L, WIN, 3), gold["geodesic_dist_L"])
+    assert ctx.preprocess_pair(5, L, R, (40, 26), detail_boost=True)
+    assert np.array_equal(ctx.download_pair(5, (26, 40, 3))[0], gold["prep_L"])
+    assert ctx.preprocess_pair(5, L, R, (24, 16), detail_boost=False)
+    assert np.array_equal(ctx.download_pair(5, (16, 24, 3))[1], gold["prep_R_noboost"])
+    ctx.upload_pair(6, L, R)
+    ctx.match_resident(6, LEFT, A.ADAPTIVE_WEIGHT, WIN, 0, D)
+    assert np.array_equal(ctx.download_disparity_u8(6, (H, W), normalize=True), gold["classic_disp_u8"])
     assert np.array_equal(np.stack(ctx.computeNCC_costs(L, R, LEFT, WIN, 0, D, normalized=False)), gold["ncc_raw"])
     assert np.array_equal(np.stack(ctx.computeNCC_costs(L, R, LEFT, WIN, 0, D)), gold["ncc"])
     assert np.array_equal(ctx.stereoMatching(L, R, LEFT, A.NCC, WIN, 0, D), gold["ncc_disp"])

@@ -408,3 +408,33 @@ def test_blo1_reference_limits(ctx):
     d0 = 5
     Ls, Rs = shifted_pair(40, 64, d0)
     assert (ctx.stereoMatching(Ls, Rs, LEFT, A.ADAPTIVE_WEIGHT_BLO1, 7, 0, 8)[8:-8, 16:-8] == d0).all()
+
+
+# ---------------------------------------------------------------- row f3: driver-side pre/post-processing on the device
+@pytest.mark.parametrize("sh,sw,dw,dh,seed", [(90, 160, 80, 45, 1), (72, 128, 64, 36, 2), (97, 131, 64, 36, 3), (360, 640, 640, 360, 4),
+                                              (50, 70, 113, 81, 5), (1080, 1920, 640, 360, 6)])
+def test_preprocess_pair(ctx, oracle, sh, sw, dw, dh, seed):
+    rng = np.random.default_rng(seed)
+    L = rng.integers(0, 256, (sh, sw, 3)).astype(np.uint8)
+    R = rng.integers(0, 256, (sh, sw, 3)).astype(np.uint8)
+    for boost in (False, True):
+        assert ctx.preprocess_pair(0, L, R, (dw, dh), detail_boost=boost)
+        gl, gr = ctx.download_pair(0, (dh, dw, 3))
+        assert np.array_equal(gl, oracle.preprocess(L, (dw, dh), boost)), boost   # u8 results: bit-exact
+        assert np.array_equal(gr, oracle.preprocess(R, (dw, dh), boost)), boost
+
+
+def test_preprocess_then_match_then_u8(ctx, oracle):
+    # the reference's main(): resize + boost, stereoMatching(..., 15, 0, 64), convertTo(8U) + normalize(0,255)
+    L, R, _ = make_pair(144, 256, 24, seed=11, block=24)
+    assert ctx.preprocess_pair(3, L, R, (128, 72), detail_boost=True)
+    ctx.match_resident(3, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 24)
+    d = ctx.download_disparity(3, (72, 128))
+    pl, pr = oracle.preprocess(L, (128, 72), True), oracle.preprocess(R, (128, 72), True)
+    rc, want = oracle.stereo_matching(pl, pr, 0, 8, 15, 0, 24)
+    assert rc == 0 and np.array_equal(d, want)
+    for norm in (False, True):
+        assert np.array_equal(ctx.download_disparity_u8(3, (72, 128), normalize=norm), oracle.disparity_to_u8(want, norm))
+    with pytest.raises(asw.AswError):   # no frame in that slot
+        ctx.download_disparity_u8(9, (72, 128))
+    assert ctx.preprocess_pair(3, L, R[:, :200], (128, 72)) is False and asw.last_status() == asw.ERR_SIZE_MISMATCH

@@ -447,3 +447,76 @@ def test_blo1_quirks(oracle):
     assert oracle.asw_blo1(L, R, 0, 0.015, 4, 0, 3)[0] == oracle.ERR_EVEN_WINDOW
     assert oracle.asw_blo1(L, R, 0, 0.015, 5, 1, 3)[0] == 7       # absolute-offset indexing: minDisparity must be 0
     assert oracle.asw_blo1(L, R, 0, 0.001, 5, 0, 3)[0] == 7       # step 0: the reference would loop forever
+
+
+# ---------------------------------------------------------------- row f3: driver-side pre/post-processing
+def test_f3_hsv_known_answers_and_round_trip(oracle):
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [128, 128, 128], [0, 0, 0], [255, 255, 255], [0, 255, 255]]], np.uint8)
+    hsv = oracle.bgr2hsv(px).reshape(-1, 3)
+    # pure red / green / blue -> H = 0 / 60 / 120 (H in [0,180)), S = V = 255; grays -> S = 0, H = 0; yellow -> H = 30
+    assert hsv.tolist() == [[0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 128], [0, 0, 0], [0, 0, 255], [30, 255, 255]]
+    assert np.array_equal(oracle.hsv2bgr(oracle.bgr2hsv(px)), px)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 60, 3)).astype(np.uint8)
+    hsv = oracle.bgr2hsv(img)
+    assert hsv[..., 0].max() < 180 and np.array_equal(hsv[..., 2], img.max(axis=2))
+    # an independent float formula (colorsys) agrees to within the 8-bit quantisation
+    import colorsys
+    for (y, x) in [(0, 0), (3, 7), (11, 19), (39, 59)]:
+        b, g, r = [int(v) / 255 for v in img[y, x]]
+        h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        dh = abs(hsv[y, x, 0] - h * 180)
+        assert min(dh, 180 - dh) <= 1 and abs(hsv[y, x, 1] - s * 255) <= 1 and abs(hsv[y, x, 2] - v * 255) <= 0.5
+    assert np.abs(oracle.hsv2bgr(hsv).astype(int) - img).max() <= 6   # H is quantised to 2 degrees
+
+
+def test_f3_resize_rules(oracle):
+    rng = np.random.default_rng(1)
+    big = rng.integers(0, 256, (90, 160, 3)).astype(np.uint8)
+    # exact 2x downscale: cv::resize executes INTER_LINEAR as INTER_AREA = rounded 2x2 average
+    half = oracle.resize_linear(big, (80, 45))
+    ref = (big[0::2, 0::2].astype(int) + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, ref)
+    # identity size: coefficients (2048, 0) -> the image itself
+    assert np.array_equal(oracle.resize_linear(big, (160, 90)), big)
+    # a constant image stays constant for any ratio (fixed-point coefficients sum to 2048 up to the truncation)
+    const = np.full((37, 53, 3), 200, np.uint8)
+    out = oracle.resize_linear(const, (31, 17))
+    assert out.shape == (17, 31, 3) and np.abs(out.astype(int) - 200).max() <= 1
+    # a horizontal ramp stays monotonic and within the input range
+    ramp = np.repeat(np.repeat((np.arange(100) * 2).astype(np.uint8)[None, :, None], 20, 0), 3, 2)
+    r2 = oracle.resize_linear(ramp, (64, 10))
+    assert (np.diff(r2[0, :, 0].astype(int)) >= 0).all() and r2.max() <= 198
+
+
+def test_f3_bilateral_and_boost(oracle):
+    dy, dx, w, lut = oracle.bilateral_tables(7, 10.0, 3.0)
+    assert len(dy) == 29 and (dy[0], dx[0]) == (-3, 0) and (dy[14], dx[14]) == (0, 0)   # circular support, raster order
+    assert w[14] == 1.0 and lut[0] == 1.0 and abs(lut[10] - np.exp(-0.5)) < 1e-7
+    flat = np.full((9, 11), 77, np.uint8)
+    assert np.array_equal(oracle.bilateral_u8(flat), flat)
+    # independent numpy evaluation of one pixel
+    rng = np.random.default_rng(2)
+    v = rng.integers(0, 256, (12, 14)).astype(np.uint8)
+    out = oracle.bilateral_u8(v)
+    pad = np.pad(v, 3, mode="symmetric")
+    y, x = 5, 6
+    s = ws = np.float32(0)
+    for k in range(29):
+        val = int(pad[y + 3 + dy[k], x + 3 + dx[k]])
+        ww = np.float32(w[k] * lut[abs(val - int(v[y, x]))])
+        s = np.float32(s + np.float32(np.float32(val) * ww)); ws = np.float32(ws + ww)
+    assert out[y, x] == int(np.rint(np.float32(s / ws)))
+    # the boost leaves a flat image alone and only ever raises V
+    img = rng.integers(0, 256, (20, 24, 3)).astype(np.uint8)
+    flat3 = np.full((8, 8, 3), 90, np.uint8)
+    assert np.array_equal(oracle.detail_boost(flat3), flat3)
+    assert (oracle.bgr2hsv(oracle.detail_boost(img))[..., 2].astype(int) >= oracle.bgr2hsv(img)[..., 2].astype(int) - 1).all()
+
+
+def test_f3_disparity_to_u8(oracle):
+    d = np.array([[0.0, 0.4, 0.5, 1.5, 2.5, 63.0, 300.0, -4.0]], np.float32)
+    assert oracle.disparity_to_u8(d, normalize=False).tolist() == [[0, 0, 0, 2, 2, 63, 255, 0]]   # cvRound: ties to even, saturate
+    d2 = np.array([[10.0, 20.0, 30.0]], np.float32)
+    assert oracle.disparity_to_u8(d2).tolist() == [[0, 128, 255]]     # 255/20*10 = 127.5 -> 128 (ties to even)
+    assert oracle.disparity_to_u8(np.full((2, 2), 7, np.float32)).tolist() == [[0, 0], [0, 0]]   # max == min -> scale 0
