@@ -150,58 +150,60 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     const uint8_t* myC = sC + (size_t)((ty + h) * LW + (tx + h)) * DC;
     const float* myWR = sWR + ty * SWR + tx + (DC - 1);
 
-    // right-weight staging positions: pass A = (row ty, j = tx); pass B (wave 0 only) = the DC-1 extra
-    // columns of all four rows.  xr = clamp(x0 - d0 - (DC-1) + j): the right pixel a weight is evaluated AT.
+    // right-weight staging positions of a tile row: pass A = column j = tx; pass B = the DC-1 extra columns.
+    // xr = clamp(x0 - d0 - (DC-1) + j): the right pixel a weight is evaluated AT.
     // Neighbour columns are clamped in tile coordinates: image column X sits at tile column X - sRx0.
     const int colLo = max(-sRx0, 0), colHi = min(W - 1 - sRx0, RW - 1);
     const int colA = min(max(x0 - d0 - (DC - 1) + tx, 0), W - 1) - sRx0;
     const uint8_t* rowA = sR + (ty + h) * RWp;
     const int ctrA = rowA[min(colA, RW - 1)];
-    constexpr int NEXTRA = TH * (DC - 1);
-    const int rowBi = (DC > 1) ? min(tx / (DC > 1 ? DC - 1 : 1), TH - 1) : 0;
-    const int jB = TW + tx - rowBi * (DC - 1);
+    // Every wavefront stages the right-image weights of ITS OWN tile row (TW + DC-1 positions: pass A = lane tx, pass B =
+    // the DC-1 extra columns, lanes 0..DC-2) and parks its own left weights: nothing in the tap-group loop is shared
+    // between wavefronts, so the loop needs no workgroup barrier -- LDS operations of one wavefront execute in order.
+    const int rowBi = ty;
+    const int jB = TW + min(tx, DC > 1 ? DC - 2 : 0);
     const int colB = min(max(x0 - d0 - (DC - 1) + jB, 0), W - 1) - sRx0;
     const uint8_t* rowB = sR + (rowBi + h) * RWp;
     const int ctrB = rowB[min(colB, RW - 1)];
     float* dstA = sWR + ty * SWR + tx;
     float* dstB = sWR + rowBi * SWR + jB;
 
+    // Software pipeline over the tap groups: the LUT gathers of group g+1 are issued (index pass + loads, nothing waits)
+    // right before the taps of group g are accumulated and are written to LDS at the top of the next iteration, so the
+    // memory round trip of the weight staging hides behind the 4 x 88 arithmetic instructions of a group.
+    const bool doB = DC > 1 && tx < DC - 1;
+    float wa[G], wlv[G], wb[G];
+    auto gather = [&](int g0) {
+        unsigned ia[G], il[G], ib[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const int4 tp = taps[g0 + t];  // uniform: scalar loads
+            // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
+            int nc = min(max(colA + tp.y, colLo), colHi);
+            ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
+            // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
+            il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
+            int ncb = min(max(colB + tp.y, colLo), colHi);
+            ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + ncb], ctrB, tp.w);
+        }
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            wa[t] = lut_at(lut, ia[t]);
+            wlv[t] = lut_at(lut, il[t]);
+            if (doB) wb[t] = lut_at(lut, ib[t]);
+        }
+    };
+    __syncthreads();  // cost tile complete
+    gather(0);
     for (int g0 = 0; g0 < p.ntaps; g0 += G) {
-        __syncthreads();  // previous group's weights consumed (first pass: cost tile complete)
-        // All LUT gathers of a group are issued back to back (index pass, gather pass, store pass): one memory round
-        // trip per group instead of one per weight.
-        {
-            unsigned ia[G], il[G];
+        // same-wavefront LDS traffic is ordered: these writes follow the previous group's reads and precede this group's
 #pragma unroll
-            for (int t = 0; t < G; t++) {
-                const int4 tp = taps[g0 + t];  // uniform: scalar loads
-                // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
-                int nc = min(max(colA + tp.y, colLo), colHi);
-                ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
-                // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
-                il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
-            }
-            float wa[G], wl[G];
-#pragma unroll
-            for (int t = 0; t < G; t++) { wa[t] = lut_at(lut, ia[t]); wl[t] = lut_at(lut, il[t]); }
-#pragma unroll
-            for (int t = 0; t < G; t++) { dstA[t * (TH * SWR)] = wa[t]; sWL[t * (TH * TW) + tid] = wl[t]; }
+        for (int t = 0; t < G; t++) {
+            dstA[t * (TH * SWR)] = wa[t];
+            sWL[t * (TH * TW) + tid] = wlv[t];
+            if (doB) dstB[t * (TH * SWR)] = wb[t];
         }
-        if (DC > 1 && tid < NEXTRA) {  // wave 0: the DC-1 extra right-weight columns of all four rows
-            unsigned ib[G];
-#pragma unroll
-            for (int t = 0; t < G; t++) {
-                const int4 tp = taps[g0 + t];
-                int nc = min(max(colB + tp.y, colLo), colHi);
-                ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + nc], ctrB, tp.w);
-            }
-            float wb[G];
-#pragma unroll
-            for (int t = 0; t < G; t++) wb[t] = lut_at(lut, ib[t]);
-#pragma unroll
-            for (int t = 0; t < G; t++) dstB[t * (TH * SWR)] = wb[t];
-        }
-        __syncthreads();
+        if (g0 + G < p.ntaps) gather(g0 + G);  // in flight while this group is accumulated
         // rolled on purpose: one tap's operands (1 + 4 + DC registers) live at a time keeps the kernel at
         // <= 128 VGPRs, i.e. 4 waves per SIMD, which hides the LDS latency better than deeper unrolling did
 #pragma unroll 1
