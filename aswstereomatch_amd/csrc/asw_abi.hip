@@ -692,12 +692,23 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pl.as<uint32_t>(), H, W, mp.win, 3, wl.as<uint16_t>()));  // M.cpp:1464
     ASW_TRY(launch_geodesic_weights_u16(ctx->stream, pr.as<uint32_t>(), H, W, mp.win, 3, wr.as<uint16_t>()));  // M.cpp:1465
+    double* partE = nullptr;
+    float* partD = nullptr;
+    if (plane <= (size_t)1 << 20) {  // small frames only: scratch for the grid.z split of the disparity range
+        DevBuf& pe = ctx->buf("bil_partE");
+        DevBuf& pd = ctx->buf("bil_partD");
+        ASW_TRY(pe.ensure((size_t)8 * plane * sizeof(double)));
+        ASW_TRY(pd.ensure((size_t)8 * plane * sizeof(float)));
+        partE = pe.as<double>(); partD = pd.as<float>();
+    }
     if (!flip)
         ASW_TRY(launch_asw_geodesic(ctx->stream, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
-                                    mp.win, mp.minD, nD, 0, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+                                    mp.win, mp.minD, nD, 0, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>(),
+                                    partE, partD));
     else
         ASW_TRY(launch_asw_geodesic(ctx->stream, pr.as<uint32_t>(), pl.as<uint32_t>(), wr.as<uint16_t>(), wl.as<uint16_t>(), H, W,
-                                    mp.win, mp.minD, nD, 1, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>()));
+                                    mp.win, mp.minD, nD, 1, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>(),
+                                    partE, partD));
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->timing.aggregate_launches = 3;
     return ASW_OK;

@@ -88,6 +88,8 @@ struct BilateralLaunch {
     int max_slices;
 };
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
+// winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d
+int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp);
 int bilateral_lds_row_stride(int win);  // LW of the kernel's sample tile (taps[].x is expressed in it)
 
 // ---- cost kernels (k_cost.hip) ----
@@ -160,7 +162,8 @@ int launch_geodesic_weights_u16(hipStream_t s, const uint32_t* img, int H, int W
 int launch_geodesic_weights_f32(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, float* planes);
 int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, int cells, float* out);
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
-                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp);
+                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE /* optional
+                        scratch [8][H][W] */, float* partD);
 
 // ---- weighted median (k_wmedian.hip) ----
 int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,

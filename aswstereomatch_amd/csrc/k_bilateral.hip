@@ -330,6 +330,13 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
 
 int bilateral_lds_row_stride(int win) { return TW + 2 * (win / 2); }
 
+int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp)
+{
+    hipLaunchKernelGGL(k_merge_slices, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, partE, partD, nz, plane, disp);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a)
 {
     switch (a.win) {

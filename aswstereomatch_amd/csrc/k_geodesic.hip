@@ -17,6 +17,8 @@
 // sum is an integer below 2^53: the f64 sums are exact in ANY order and E = num/den is bit-identical
 // to the reference whatever the schedule.  Tiling follows the bilateral kernel (64x4 pixel tile, DC
 // disparities per thread, taps outer); wR rows are staged through LDS from the weight planes.
+#include <algorithm>
+
 #include "asw_internal.h"
 
 namespace {
@@ -150,6 +152,7 @@ constexpr int TW = 64, TH = 4, GG = 5;  // tile, taps per staging group; GDC = w
 struct GeoParams {
     int H, W, win, minD, nD;
     int flip;  // 1: mirrored problem (DISPARITY_RIGHT): images / weight planes are read at W-1-x, window columns reversed
+    int cand_per_z;  // candidates per grid.z slice (multiple of 16): small frames split the d range over grid.z
 };
 
 template <int DC, int GDC>
@@ -296,7 +299,7 @@ template <int GDC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_asw_geodesic(GeoParams p, const uint32_t* __restrict__ imgL,
                                                       const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
                                                       const uint16_t* __restrict__ wR, float* __restrict__ vol,
-                                                      float* __restrict__ disp)
+                                                      float* __restrict__ disp, double* __restrict__ partE, float* __restrict__ partD)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int h = p.win / 2, TR = TH + 2 * h, LW = TW + 2 * h;
@@ -310,15 +313,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     double bestE = 1.7976931348623157e308;
     float bestD = 0.0f;
-    int c0 = 0;
+    int c0 = blockIdx.z * p.cand_per_z;  // this workgroup's candidate range: all of it, or one grid.z slice for small frames
+    const int cEnd = min(p.nD, c0 + p.cand_per_z);
     if constexpr (GDC >= 16)
-        for (; c0 + 16 <= p.nD; c0 += 16) geo_chunk<16, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
-    for (; c0 + 8 <= p.nD; c0 += 8) geo_chunk<8, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
-    if (p.nD - c0 >= 4) { geo_chunk<4, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
-    if (p.nD - c0 >= 2) { geo_chunk<2, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
-    if (p.nD - c0 >= 1) { geo_chunk<1, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
+        for (; c0 + 16 <= cEnd; c0 += 16) geo_chunk<16, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    for (; c0 + 8 <= cEnd; c0 += 8) geo_chunk<8, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
+    if (cEnd - c0 >= 4) { geo_chunk<4, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 4; }
+    if (cEnd - c0 >= 2) { geo_chunk<2, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 2; }
+    if (cEnd - c0 >= 1) { geo_chunk<1, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD); c0 += 1; }
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
-    if (x < p.W && y < p.H) disp[(size_t)y * p.W + (p.flip ? p.W - 1 - x : x)] = bestD;
+    if (x < p.W && y < p.H) {
+        const size_t o = (size_t)y * p.W + (p.flip ? p.W - 1 - x : x);
+        if (gridDim.z == 1) {
+            disp[o] = bestD;
+        } else {  // per-slice winners, merged by launch_merge_slices
+            partE[(size_t)blockIdx.z * p.H * p.W + o] = bestE;
+            partD[(size_t)blockIdx.z * p.H * p.W + o] = bestD;
+        }
+    }
 }
 
 template <int WIN, typename OutT>
@@ -380,25 +392,35 @@ size_t geo_lds_bytes(int win)
     return (size_t)2 * GG * TH * (TW + GDC - 1) * 4 + (size_t)TR * LW * 4 + (size_t)TR * RWmax * 4;
 }
 template <int GDC>
-int launch_geo_t(hipStream_t s, const GeoParams& p, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
-                 const uint16_t* wR, float* vol, float* disp)
+int launch_geo_t(hipStream_t s, GeoParams p, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
+                 const uint16_t* wR, float* vol, float* disp, double* partE, float* partD)
 {
     const size_t lds = geo_lds_bytes<GDC>(p.win);
     auto kern = k_asw_geodesic<GDC>;
     if (lds > 64 * 1024)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, imgL, imgR, wL, wR, vol, disp);
+    // frames with few tiles (KITTI: 1880 for 1024 resident workgroups) split the candidate range over grid.z in
+    // multiples of 16 until there are ~4096 workgroups; a second tiny launch merges the per-slice winners
+    const int tiles = grid.x * grid.y, chunks16 = (p.nD + 15) / 16;
+    int nz = 1;
+    if (partE && partD && tiles < 4096) nz = std::min(chunks16, std::min(8, (4096 + tiles - 1) / tiles));
+    const int chunks_per_z = (chunks16 + nz - 1) / nz;
+    nz = (chunks16 + chunks_per_z - 1) / chunks_per_z;
+    p.cand_per_z = chunks_per_z * 16;
+    grid.z = nz;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, imgL, imgR, wL, wR, vol, disp, partE, partD);
     ASW_HIP_TRY(hipGetLastError());
+    if (nz > 1) return launch_merge_slices(s, partE, partD, nz, (size_t)p.H * p.W, disp);
     return ASW_OK;
 }
 }  // namespace
 
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
-                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp)
+                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE, float* partD)
 {
-    GeoParams p{H, W, win, minD, nD, flip};
+    GeoParams p{H, W, win, minD, nD, flip, 0};
     // 16-wide d-chunks: 25 KB of LDS at win 15 (45 KB at win 35)
-    if (geo_lds_bytes<16>(win) <= 160 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp);
+    if (geo_lds_bytes<16>(win) <= 160 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp, partE, partD);
     return ASW_ERR_BAD_ARGUMENT;
 }
