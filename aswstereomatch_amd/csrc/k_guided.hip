@@ -46,7 +46,9 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 {
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wavefront index is uniform within a wavefront: as an SGPR it makes strip, band, slice and every base address
+    // derived from them scalar
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* hs = reinterpret_cast<double*>(smem) + (size_t)wv * ND * NP * (SW + 2);  // [ND][NP][SW+2] per wavefront
     const int hl = k / 2;  // OpenCV anchor = k/2 (also for even k)
     const int XO = SW - (k - 1);
