@@ -103,3 +103,38 @@ def test_batch_equals_single_frames(ctx):
     for (L, R), o in zip(frames, outs):
         assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7, 0, 24))
     assert asw.stereoMatchingBatch([], [], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) == []
+
+
+def test_rows_f1_f4_mid_size_vs_oracle(ctx, oracle):
+    # the methods added by rows f1 / f4, at sizes the oracle finishes in seconds; the bit-exact ones are compared bit for bit
+    L, R, _ = make_pair(360, 640, 48, seed=77)
+    rc, dw, vw = oracle.asw_direct8(L, R, 0, 15, 0, 48, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_direct8(L, R, LEFT, 15, 0, 48, return_cost_volume=True)
+    assert rc == 0 and np.array_equal(v, vw) and np.array_equal(d, dw)
+    L, R, _ = make_pair(180, 320, 32, seed=78)
+    rc, want = oracle.cost_ncc(L, R, 0, 15, 0, 32, raw=True)
+    got = np.stack(ctx.computeNCC_costs(L, R, LEFT, 15, 0, 32, normalized=False))
+    assert rc == 0 and np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(ctx.computeNCC(L, R, LEFT, 15, 0, 32), oracle.ncc_disparity(L, R, 0, 15, 0, 32)[1])
+    rc, dw, vw = oracle.asw_guided3(L, R, 0, 1e-6, 15, 0, 32, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_GuidedF_3(L, R, LEFT, 1e-6, 15, 0, 32, return_cost_volume=True)
+    assert rc == 0 and np.allclose(v, vw, rtol=1e-4, atol=1e-30) and np.array_equal(d, dw)
+    L, R, _ = make_pair(135, 240, 16, seed=79)
+    rc, dw, vw = oracle.asw_blo1(L, R, 0, 0.015, 15, 0, 16, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.015, 15, 0, 16, return_cost_volume=True)
+    fin = np.isfinite(vw)
+    assert rc == 0 and np.array_equal(v[fin], vw[fin]) and np.array_equal(d, dw)
+
+
+def test_1080p_new_methods_properties(ctx):
+    # full-size runs of the f1 / f4 methods: WTA consistency of the returned volume and bit determinism
+    L, R, _ = make_pair(1080, 1920, 64, seed=80)
+    for alg, ncand in [(A.ADAPTIVE_WEIGHT_8DIRECT, 65), (A.ADAPTIVE_WEIGHT_BLO1, 64), (A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, 64)]:
+        d, v = ctx.stereoMatching(L, R, LEFT, alg, 15, 0, 64, return_cost_volume=True)
+        assert v.shape == (ncand, 1080, 1920) and _wta_consistent(d, v), alg
+        assert np.array_equal(d, ctx.stereoMatching(L, R, LEFT, alg, 15, 0, 64)), alg
+    # the driver pipeline of main(): 1080p pair -> 640x360, boosted, matched, u8 disparity
+    assert ctx.preprocess_pair(2, L, R, (640, 360), detail_boost=True)
+    ctx.match_resident(2, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 64)
+    d8 = ctx.download_disparity_u8(2, (360, 640), normalize=True)
+    assert d8.dtype == np.uint8 and d8.min() == 0 and d8.max() == 255
