@@ -1,14 +1,9 @@
 // Streaming kernels: BGR->gray, AD / TAD cost volumes, WTA arg-min.  All HBM-bound, integer-exact.
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{  // cv::BORDER_REFLECT, repeated
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
 
 // cvtColor(COLOR_BGR2GRAY) 8U, OpenCV 4.1.0 14-bit fixed point (M.cpp:1031-1033; App. A-1)
 __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray, uint32_t k0, uint32_t k2)

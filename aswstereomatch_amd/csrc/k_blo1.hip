@@ -12,22 +12,11 @@
 // exactly the association of the CPU restatement.  A workgroup owns a 64 x 4 tile and walks the disparity indices in
 // chunks of DC: per chunk the shifted view (DC bytes per cell) and the SAD costs (DC floats per cell) of the tile + halo
 // are staged in LDS with the REFLECT_101 box border and the REFLECT shift border already applied.
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{  // BORDER_REFLECT (App. A-2): the shift of the other view, M.cpp:2566-2573
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
-__device__ __forceinline__ int reflect101_idx(int p, int len)
-{  // BORDER_REFLECT_101: boxFilter's default border
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
 
 constexpr int BTW = 64, BTH = 4;
 

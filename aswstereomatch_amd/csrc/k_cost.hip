@@ -5,22 +5,11 @@
 // library is compiled with -ffp-contract=off so no a*b+c is fused behind our back.
 #include <math.h>
 
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{  // BORDER_REFLECT (App. A-2)
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
-__device__ __forceinline__ int reflect101_idx(int p, int len)
-{  // BORDER_REFLECT_101 (App. A-3)
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
 
 // filter2D(8UC3 -> CV_32F, [-3 0 3; -10 0 10; -3 0 3]), BORDER_REFLECT_101, on the image padded on
 // the left by `pad` REFLECT columns (pad = 0 for the left image, max_offset for the right one:

@@ -19,18 +19,13 @@
 // disparities per thread, taps outer); wR rows are staged through LDS from the weight planes.
 #include <algorithm>
 
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
 constexpr uint32_t GEO_INF = 0x40000000u;
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
 
 __global__ __launch_bounds__(256) void k_pack_bgrx(const uint8_t* __restrict__ bgr, size_t n, uint32_t* __restrict__ out)
 {

@@ -13,22 +13,11 @@
 // The kernels are bound by f64 VALU + HBM streaming of the a/b planes, see DESIGN.md.
 #include <stdlib.h>
 
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
-__device__ __forceinline__ int reflect101_idx(int p, int len)
-{
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
 
 constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 

@@ -12,16 +12,11 @@
 // walks the window row-major (the order the CPU restatement adds in), so per tap and candidate it spends one LDS read,
 // one f32 subtract, one f32 multiply, one convert and one f64 add.  No MFMA: the subtraction of a per-pixel mean
 // inside the product and the f32 rounding of every product keep this from being a contraction.
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{  // BORDER_REFLECT (App. A-2)
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
 
 // copyMakeBorder(gray, 0, 0, padL, padR, BORDER_REFLECT)  (M.cpp:852, 882)
 __global__ __launch_bounds__(256) void k_pad_gray(const uint8_t* __restrict__ g, int H, int W, int padL, int Wp,

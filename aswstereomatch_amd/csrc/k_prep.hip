@@ -5,16 +5,11 @@
 // and the disparity can be downloaded as one byte per pixel.  All kernels are streaming (HBM-bound); every arithmetic
 // step is integer or f32 arithmetic in a fixed order (-ffp-contract=off).  The OpenCV 4.1.0 semantics followed here
 // (portable C++ paths of resize, cvtColor, bilateralFilter, normalize) cannot be verified offline: DESIGN.md section 2.
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{  // BORDER_REFLECT
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
 __device__ __forceinline__ int sat_u8(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int floor_f(float v)
 {

@@ -16,16 +16,11 @@
 // [y][x][cell] (900 contiguous bytes per pixel -> coalesced): the left one premultiplied by the space
 // kernel once per frame, the right one for the REFLECT-padded right image (M.cpp:3246, 3263).
 // exp() values come from host-built tables (same libm as the oracle), so weights are bit-identical.
+#include "asw_device.h"
 #include "asw_internal.h"
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int len)
-{
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
-    return p;
-}
 
 // colour weights of every window cell: out[(y*Wimg + c)*n + cell]
 //   pad = 0:  left image, multiplied by the space kernel wd[cell]           (M.cpp:3262, 3274)
