@@ -1,0 +1,107 @@
+"""Randomised GPU-vs-oracle parity sweep (not part of the pytest suite: run it on the GPU box when kernels change).
+
+    python tools/fuzz_parity.py --seconds 120 --seed 1
+
+Every method of the selector is run through the C-ABI on random shapes / windows / disparity ranges / directions and
+compared with the CPU oracle: WTA index bit-exact everywhere; cost volume bit-exact for the methods whose summation
+order the kernels reproduce, within 1e-4 (relative) for the guided-filter family.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import aswstereomatch_amd as asw  # noqa: E402
+from aswstereomatch_amd.synth import make_pair  # noqa: E402
+from oracle import asw_oracle as O  # noqa: E402
+
+A = asw.StereoMatchingAlgorithms
+
+
+def close(a, b):
+    fin = np.isfinite(b)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(a[fin], b[fin], rtol=1e-4, atol=1e-30)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    ctx = asw.Context(0)
+    O.set_threads(min(16, O.max_threads()))
+    t0 = time.time()
+    n = fails = 0
+    counts = {}
+    while time.time() - t0 < args.seconds:
+        H = int(rng.integers(1, 70))
+        W = int(rng.integers(1, 260))
+        win = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 21]))
+        minD = int(rng.choice([0, 0, 0, 1, 3]))
+        numD = int(rng.integers(1, 48))
+        dt = int(rng.integers(0, 2))
+        seed = int(rng.integers(0, 1 << 30))
+        L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
+        method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost"]))
+        tag = (method, H, W, win, minD, numD, dt, seed)
+        try:
+            if method == "classic":
+                rc, dw, vw = O.asw_classic(L, R, 30, 20, dt, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, win, minD, numD, return_cost_volume=True)
+                ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+            elif method == "direct8":
+                rc, dw, vw = O.asw_direct8(L, R, 0, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_direct8(L, R, 0, win, minD, numD, return_cost_volume=True)
+                ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+            elif method == "geodesic":
+                win = min(win, 15)
+                rc, dw, vw = O.asw_geodesic(L, R, dt, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, win, minD, numD, return_cost_volume=True)
+                ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+            elif method == "guided":
+                rc, dw, vw = O.asw_guided(L, R, dt, 1e-6, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, win, minD, numD, return_cost_volume=True)
+                ok = close(v, vw) and np.array_equal(d, dw)
+            elif method == "guided2":
+                rc, dw, vw = O.asw_guided2(L, R, 0, 1e-6, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, 0, 1e-6, win, minD, numD, return_cost_volume=True)
+                ok = close(v, vw) and np.array_equal(d, dw)
+            elif method == "guided3":
+                rc, dw, vw = O.asw_guided3(L, R, dt, 1e-6, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_GuidedF_3(L, R, dt, 1e-6, win, minD, numD, return_cost_volume=True)
+                # flat windows make NaN costs: their WTA is build-defined on both sides, compare where finite
+                ok = close(v, vw) and np.array_equal(d[np.isfinite(vw).all(axis=0)], dw[np.isfinite(vw).all(axis=0)])
+            elif method == "wmedian":
+                win = min(win, 17)
+                rc, dw, vw = O.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, 0, win, 10, 10, minD, numD, return_cost_volume=True)
+                ok = np.array_equal(v, vw) and np.array_equal(d, dw)
+            elif method == "blo1":
+                rc, dw, vw = O.asw_blo1(L, R, dt, 0.015, win, 0, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_BLO1(L, R, dt, 0.015, win, 0, numD, return_cost_volume=True)
+                fin = np.isfinite(vw)
+                ok = np.array_equal(v[fin], vw[fin]) and np.array_equal(np.isnan(v), np.isnan(vw)) and np.array_equal(d, dw)
+            elif method == "ncc":
+                rc, dw = O.ncc_disparity(L, R, dt, win, minD, numD)
+                ok = np.array_equal(ctx.computeNCC(L, R, dt, win, minD, numD), dw)
+            else:
+                rc, vw = O.cost_ncc(L, R, dt, win, minD, numD)
+                ok = np.array_equal(np.stack(ctx.computeNCC_costs(L, R, dt, win, minD, numD)), vw, equal_nan=True)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            print("EXC", tag, repr(e), flush=True)
+        n += 1
+        counts[method] = counts.get(method, 0) + 1
+        if not ok:
+            fails += 1
+            print("MISMATCH", tag, flush=True)
+    print("cases", n, "failures", fails, counts)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
