@@ -30,6 +30,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-h", type=int, default=70)
+    ap.add_argument("--max-w", type=int, default=260)
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = asw.Context(0)
@@ -38,15 +40,16 @@ def main():
     n = fails = 0
     counts = {}
     while time.time() - t0 < args.seconds:
-        H = int(rng.integers(1, 70))
-        W = int(rng.integers(1, 260))
+        H = int(rng.integers(1, args.max_h))
+        W = int(rng.integers(1, args.max_w))
         win = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 21]))
         minD = int(rng.choice([0, 0, 0, 1, 3]))
         numD = int(rng.integers(1, 48))
         dt = int(rng.integers(0, 2))
         seed = int(rng.integers(0, 1 << 30))
         L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
-        method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost"]))
+        method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
+                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
         try:
             if method == "classic":
@@ -88,6 +91,33 @@ def main():
             elif method == "ncc":
                 rc, dw = O.ncc_disparity(L, R, dt, win, minD, numD)
                 ok = np.array_equal(ctx.computeNCC(L, R, dt, win, minD, numD), dw)
+            elif method == "ad_tad":
+                rc, vw = O.compute_ad(L, R, dt, minD, numD)
+                rc, tw = O.compute_tad(L, R, dt, 30, minD, numD)
+                ok = (np.array_equal(np.stack(ctx.computeAD(L, R, dt, minD, numD)), vw) and
+                      np.array_equal(np.stack(ctx.computeTAD(L, R, dt, 30, minD, numD)), tw))
+            elif method == "similarity":
+                rc, vw = O.compute_similarity(L, R, 0.4, 10, 50, 0, minD, numD)
+                ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, 0, minD, numD)), vw)
+            elif method == "sad":
+                rc, vw = O.cost_sad(L, R, dt, win, minD, numD)
+                ok = np.array_equal(np.stack(ctx.getCostSAD(L, R, dt, win, minD, numD)), vw)
+            elif method == "geodist":
+                win = min(win, 15)
+                rc, vw = O.geodesic_dist(L, win, 3)
+                ok = np.array_equal(ctx.getGeodesicDist(L, win, 3), vw)
+            elif method == "gfilter":
+                P = rng.random((H, W), dtype=np.float32)
+                guide = L if dt == 0 else np.concatenate([L, R], axis=2)
+                rc, qw = O.guided_filter(guide, P, max(win, 1), 1e-6)
+                q = ctx.getGuidedFilter(guide, P, max(win, 1), 1e-6)
+                ok = close(q, qw)
+            elif method == "prep":
+                dw_, dh_ = int(rng.integers(1, 2 * W + 2)), int(rng.integers(1, 2 * H + 2))
+                boost = bool(dt)
+                ok = bool(ctx.preprocess_pair(7, L, R, (dw_, dh_), detail_boost=boost))
+                gl, gr = ctx.download_pair(7, (dh_, dw_, 3))
+                ok = ok and np.array_equal(gl, O.preprocess(L, (dw_, dh_), boost)) and np.array_equal(gr, O.preprocess(R, (dw_, dh_), boost))
             else:
                 rc, vw = O.cost_ncc(L, R, dt, win, minD, numD)
                 ok = np.array_equal(np.stack(ctx.computeNCC_costs(L, R, dt, win, minD, numD)), vw, equal_nan=True)
