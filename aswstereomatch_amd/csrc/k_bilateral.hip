@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "asw_internal.h"
 
@@ -173,19 +174,25 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     // memory round trip of the weight staging hides behind the 4 x 88 arithmetic instructions of a group.
     const bool doB = DC > 1 && tx < DC - 1;
     float wa[G], wlv[G], wb[G];
+    // Tiles whose shifted window lies inside the image need no clamping of the neighbour column (most of them)
+    const bool interior = x0 - h - (d0 + DC - 1) >= 0 && x0 + TW + h - d0 <= W;
     auto gather = [&](int g0) {
         unsigned ia[G], il[G], ib[G];
+        auto index_pass = [&](auto is_interior) {
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            const int4 tp = taps[g0 + t];  // uniform: scalar loads
-            // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
-            int nc = min(max(colA + tp.y, colLo), colHi);
-            ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
-            // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
-            il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
-            int ncb = min(max(colB + tp.y, colLo), colHi);
-            ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + ncb], ctrB, tp.w);
-        }
+            for (int t = 0; t < G; t++) {
+                const int4 tp = taps[g0 + t];  // uniform: scalar loads
+                // right-image weights (M.cpp:1063,1066): |gR(neighbour of xr) - gR(xr)| + class*256 -> LUT
+                const int nc = decltype(is_interior)::value ? colA + tp.y : min(max(colA + tp.y, colLo), colHi);
+                ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
+                // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
+                il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
+                const int ncb = decltype(is_interior)::value ? colB + tp.y : min(max(colB + tp.y, colLo), colHi);
+                ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + ncb], ctrB, tp.w);
+            }
+        };
+        if (interior) index_pass(std::true_type());
+        else index_pass(std::false_type());
 #pragma unroll
         for (int t = 0; t < G; t++) {
             wa[t] = lut_at(lut, ia[t]);
