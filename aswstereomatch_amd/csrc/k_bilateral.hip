@@ -161,23 +161,27 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     // Every wavefront stages the right-image weights of ITS OWN tile row (TW + DC-1 positions: pass A = lane tx, pass B =
     // the DC-1 extra columns, lanes 0..DC-2) and parks its own left weights: nothing in the tap-group loop is shared
     // between wavefronts, so the loop needs no workgroup barrier -- LDS operations of one wavefront execute in order.
-    const int rowBi = ty;
-    const int jB = TW + min(tx, DC > 1 ? DC - 2 : 0);
+    // Pass B handles the extra columns of all G taps of a group in ONE round: lane -> (tap slot tB, extra column jj),
+    // G*(DC-1) <= 64 lanes; the tap parameters of that lane's slot come from a per-lane load of the tap table.
+    constexpr int NB = DC > 1 ? DC - 1 : 1;
+    const int tB = min(tx / NB, G - 1);
+    const int jB = TW + min(tx - tB * NB, NB - 1);
     const int colB = min(max(x0 - d0 - (DC - 1) + jB, 0), W - 1) - sRx0;
-    const uint8_t* rowB = sR + (rowBi + h) * RWp;
+    const uint8_t* rowB = sR + (ty + h) * RWp;
     const int ctrB = rowB[min(colB, RW - 1)];
     float* dstA = sWR + ty * SWR + tx;
-    float* dstB = sWR + rowBi * SWR + jB;
+    float* dstB = sWR + tB * (TH * SWR) + ty * SWR + jB;
 
     // Software pipeline over the tap groups: the LUT gathers of group g+1 are issued (index pass + loads, nothing waits)
     // right before the taps of group g are accumulated and are written to LDS at the top of the next iteration, so the
     // memory round trip of the weight staging hides behind the 4 x 88 arithmetic instructions of a group.
-    const bool doB = DC > 1 && tx < DC - 1;
-    float wa[G], wlv[G], wb[G];
+    const bool doB = DC > 1 && tx < G * NB;
+    float wa[G], wlv[G], wb = 0.0f;
     // Tiles whose shifted window lies inside the image need no clamping of the neighbour column (most of them)
     const bool interior = x0 - h - (d0 + DC - 1) >= 0 && x0 + TW + h - d0 <= W;
     auto gather = [&](int g0) {
-        unsigned ia[G], il[G], ib[G];
+        unsigned ia[G], il[G], ib;
+        const int4 tpb = taps[g0 + tB];  // this lane's tap slot of pass B (vector load, L1-resident table)
         auto index_pass = [&](auto is_interior) {
 #pragma unroll
             for (int t = 0; t < G; t++) {
@@ -187,9 +191,9 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
                 ia[t] = __builtin_amdgcn_sad_u16((int)rowA[tp.z * RWp + nc], ctrA, tp.w);
                 // this thread's own left-image weight (M.cpp:1062,1065), parked in LDS until its tap comes up
                 il[t] = __builtin_amdgcn_sad_u16((int)myL[tp.z * LWp + tp.y], ctrL, tp.w);
-                const int ncb = decltype(is_interior)::value ? colB + tp.y : min(max(colB + tp.y, colLo), colHi);
-                ib[t] = __builtin_amdgcn_sad_u16((int)rowB[tp.z * RWp + ncb], ctrB, tp.w);
             }
+            const int ncb = decltype(is_interior)::value ? colB + tpb.y : min(max(colB + tpb.y, colLo), colHi);
+            ib = __builtin_amdgcn_sad_u16((int)rowB[__mul24(tpb.z, RWp) + ncb], ctrB, tpb.w);
         };
         if (interior) index_pass(std::true_type());
         else index_pass(std::false_type());
@@ -197,8 +201,8 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
         for (int t = 0; t < G; t++) {
             wa[t] = lut_at(lut, ia[t]);
             wlv[t] = lut_at(lut, il[t]);
-            if (doB) wb[t] = lut_at(lut, ib[t]);
         }
+        if (doB) wb = lut_at(lut, ib);
     };
     __syncthreads();  // cost tile complete
     gather(0);
@@ -208,8 +212,8 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
         for (int t = 0; t < G; t++) {
             dstA[t * (TH * SWR)] = wa[t];
             sWL[t * (TH * TW) + tid] = wlv[t];
-            if (doB) dstB[t * (TH * SWR)] = wb[t];
         }
+        if (doB) *dstB = wb;
         if (g0 + G < p.ntaps) gather(g0 + G);  // in flight while this group is accumulated
         // rolled on purpose: one tap's operands (1 + 4 + DC registers) live at a time keeps the kernel at
         // <= 128 VGPRs, i.e. 4 waves per SIMD, which hides the LDS latency better than deeper unrolling did
