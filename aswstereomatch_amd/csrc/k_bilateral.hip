@@ -118,19 +118,30 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
         sR[r * RWp + c] = gR[(size_t)yy * W + (p.flip ? W - 1 - xx : xx)];
     }
     __syncthreads();
+    // Tiles whose (shifted) windows lie inside the image need no clamping (most of them): `interior` for the right-image
+    // weights (positions x - d and their neighbours), `interiorC` for the cost tile (left pixels x0-h .. x0+TW+h-1 too)
+    const bool interior = x0 - h - (d0 + DC - 1) >= 0 && x0 + TW + h - d0 <= W;
+    const bool interiorC = x0 - h - (d0 + DC - 1) >= 0 && x0 + TW + h <= W;
     // cost tile: C[r][c][dd] = |gL(ny,nx) - gR(ny, max(0, nx-d))|   (M.cpp:1106)
     for (int i = tid; i < TR * LW; i += 256) {
         int r = i / LW, c = i - r * LW;
-        int nx = min(max(x0 - h + c, 0), W - 1);
-        int gl = sL[r * LWp + c];
+        const uint32_t gl = sL[r * LWp + c];
         uint32_t pk[(DC + 3) / 4];
 #pragma unroll
         for (int q = 0; q < (DC + 3) / 4; q++) pk[q] = 0;
+        if (interiorC) {  // right pixel of candidate dd sits at tile column c + DC-1-dd: |a - b| with the byte SAD unit
+            const uint8_t* q = sR + r * RWp + c + (DC - 1);
 #pragma unroll
-        for (int dd = 0; dd < DC; dd++) {
-            int xr = max(0, nx - (d0 + dd));
-            int v = abs(gl - (int)sR[r * RWp + min(xr - sRx0, RW - 1)]);
-            pk[dd >> 2] |= (uint32_t)v << (8 * (dd & 3));
+            for (int dd = 0; dd < DC; dd++)
+                pk[dd >> 2] |= __builtin_amdgcn_sad_u8(gl, (uint32_t)q[-dd], 0u) << (8 * (dd & 3));
+        } else {
+            int nx = min(max(x0 - h + c, 0), W - 1);
+#pragma unroll
+            for (int dd = 0; dd < DC; dd++) {
+                int xr = max(0, nx - (d0 + dd));
+                int v = abs((int)gl - (int)sR[r * RWp + min(xr - sRx0, RW - 1)]);
+                pk[dd >> 2] |= (uint32_t)v << (8 * (dd & 3));
+            }
         }
         if constexpr (DC >= 4) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(sC + (size_t)i * DC);
@@ -177,8 +188,6 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
     // memory round trip of the weight staging hides behind the 4 x 88 arithmetic instructions of a group.
     const bool doB = DC > 1 && tx < G * NB;
     float wa[G], wlv[G], wb = 0.0f;
-    // Tiles whose shifted window lies inside the image need no clamping of the neighbour column (most of them)
-    const bool interior = x0 - h - (d0 + DC - 1) >= 0 && x0 + TW + h - d0 <= W;
     auto gather = [&](int g0) {
         unsigned ia[G], il[G], ib;
         const int4 tpb = taps[g0 + tB];  // this lane's tap slot of pass B (vector load, L1-resident table)
