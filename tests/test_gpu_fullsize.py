@@ -103,6 +103,12 @@ def test_batch_equals_single_frames(ctx):
     for (L, R), o in zip(frames, outs):
         assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7, 0, 24))
     assert asw.stereoMatchingBatch([], [], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) == []
+    # every method of the selector goes through the same scheduler
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_BLO1,
+                A.ADAPTIVE_WEIGHT_GUIDED_FILTER, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.ADAPTIVE_WEIGHT_MEDIAN, A.NCC):
+        outs = asw.stereoMatchingBatch([f[0] for f in frames[:3]], [f[1] for f in frames[:3]], LEFT, alg, 7, 0, 12, device_ids=[0, 0])
+        for (L, R), o in zip(frames[:3], outs):
+            assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 12)), alg
 
 
 def test_rows_f1_f4_mid_size_vs_oracle(ctx, oracle):
