@@ -18,7 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference is MSVC/SSE2 code that never fuses a*b+c, and the parity
 # oracle is built the same way; fused forms are written explicitly where they are provably exact.
 CXXFLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
 ]
 

@@ -21,6 +21,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: only the entry points below are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -200,5 +205,9 @@ int asw_stereo_match_batch(int n_frames, const asw_image* lefts, const asw_image
 
 #ifdef __cplusplus
 }
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* ASW_MI355X_H */

@@ -26,6 +26,14 @@ def test_header_symbols_are_exported(so):
         assert hasattr(so, name), name
 
 
+def test_only_the_abi_is_exported(so):
+    # built with -fvisibility=hidden: the dynamic symbol table holds the C-ABI and nothing else of ours
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T"}
+    assert funcs == set(_lib.ABI_SYMBOLS), funcs ^ set(_lib.ABI_SYMBOLS)
+
+
 def test_enum_values_match_reference():
     # parametersStereo.h:4-24
     A = asw.StereoMatchingAlgorithms
