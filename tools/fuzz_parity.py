@@ -39,6 +39,7 @@ def main():
     t0 = time.time()
     n = fails = 0
     counts = {}
+    last = t0
     while time.time() - t0 < args.seconds:
         H = int(rng.integers(1, args.max_h))
         W = int(rng.integers(1, args.max_w))
@@ -126,6 +127,9 @@ def main():
             print("EXC", tag, repr(e), flush=True)
         n += 1
         counts[method] = counts.get(method, 0) + 1
+        if time.time() - last > 30:  # a line now and then: long silent runs look hung to the job runner
+            last = time.time()
+            print("progress: %d cases, %d failures, %.0f s" % (n, fails, last - t0), flush=True)
         if not ok:
             fails += 1
             print("MISMATCH", tag, flush=True)
