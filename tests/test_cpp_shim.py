@@ -8,6 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "shim_demo")
+CEXE = os.path.join(ROOT, "tests", "cpp", "abi_demo")
 
 
 def _build():
@@ -18,6 +19,44 @@ def _build():
            "-L" + os.path.join(ROOT, "aswstereomatch_amd"), "-lasw_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "aswstereomatch_amd"),
            "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
     subprocess.check_call(cmd)
+
+
+def _build_c():
+    from aswstereomatch_amd import build
+
+    build.build()
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "abi_demo.c"), "-L" + os.path.join(ROOT, "aswstereomatch_amd"), "-lasw_mi355x",
+           "-Wl,-rpath," + os.path.join(ROOT, "aswstereomatch_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", CEXE]
+    subprocess.check_call(cmd)
+
+
+def test_abi_header_is_plain_c99():
+    # the drop-in boundary: no C++, no torch, no OpenCV types -- a C99 translation unit includes the header and links
+    _build_c()
+    assert os.path.exists(CEXE)
+
+
+@pytest.mark.gpu
+def test_c_program_matches_ctypes_path(tmp_path):
+    import aswstereomatch_amd as asw
+    from aswstereomatch_amd.synth import make_pair
+    from oracle import asw_oracle as O
+
+    if not os.path.exists(CEXE):
+        _build_c()
+    L, R, _ = make_pair(36, 64, 10, seed=6, block=12)
+    L.tofile(tmp_path / "l.raw")
+    R.tofile(tmp_path / "r.raw")
+    ctx = asw.Context(0)
+    for alg in (2, 3, 10):
+        r = subprocess.run([CEXE, "36", "64", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(alg), "7", "0", "10",
+                            str(tmp_path / "d.raw"), str(tmp_path / "d8.raw")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.startswith("ok 36 64"), (r.stdout, r.stderr)
+        want = ctx.stereoMatching(L, R, asw.DISPARITY_LEFT, alg, 7, 0, 10)
+        assert np.array_equal(np.fromfile(tmp_path / "d.raw", np.float32).reshape(36, 64), want)
+        assert np.array_equal(np.fromfile(tmp_path / "d8.raw", np.uint8).reshape(36, 64), O.disparity_to_u8(want, True))
+    ctx.close()
 
 
 def test_shim_compiles_without_opencv():
