@@ -237,6 +237,12 @@ class Context:
         return self._cost(self._lib.asw_cost_tad, "asw_cost_tad", leftImg, rightImg, np.uint8, a.shape[:2], numDisparity,
                           (int(dispType), threshold_T, minDisparity, numDisparity))
 
+    def computeSD(self, leftImg, rightImg, dispType=DISPARITY_LEFT, minDisparity=0, numDisparity=30):
+        """Squared differences (M.cpp:670-759): the AD plane multiplied by itself in u8, saturating at 255."""
+        a = np.asarray(leftImg)
+        return self._cost(self._lib.asw_cost_sd, "asw_cost_sd", leftImg, rightImg, np.uint8, a.shape[:2], numDisparity,
+                          (int(dispType), minDisparity, numDisparity))
+
     def computeSimilarity(self, leftImg, rightImg, regularity, thresC, thresG, dispType, minDisparity, numDisparity,
                           winSize=None):
         """Both overloads of computeSimilarity (M.cpp:415, 651); winSize selects the padded one."""

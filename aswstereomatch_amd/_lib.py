@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_direct8", "asw_aggregate_guided3",
     "asw_cost_ncc", "asw_ncc_disparity",
     "asw_preprocess_pair", "asw_download_pair", "asw_download_disparity_u8",
-    "asw_cost_ad", "asw_cost_tad", "asw_cost_similarity", "asw_cost_sad",
+    "asw_cost_ad", "asw_cost_tad", "asw_cost_sd", "asw_cost_similarity", "asw_cost_sad",
     "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray",
     "asw_stereo_match_batch",
 ]
@@ -87,6 +87,7 @@ def lib():
         l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P]
         l.asw_aggregate_blo1.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_cost_ad.argtypes = [P, IMG, IMG, P, I, I, I]
+        l.asw_cost_sd.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_cost_tad.argtypes = [P, IMG, IMG, P, I, I, I, I]
         l.asw_cost_similarity.argtypes = [P, IMG, IMG, P, D, D, D, I, I, I, I]
         l.asw_cost_sad.argtypes = [P, IMG, IMG, P, I, I, I, I]

@@ -93,6 +93,12 @@ extern "C" int asw_cost_tad(asw_ctx* ctx, const asw_image* left, const asw_image
     return cost_ad_common(ctx, left, right, cost, disparity_type, 1, threshold_t, min_disparity, num_disparity);
 }
 
+extern "C" int asw_cost_sd(asw_ctx* ctx, const asw_image* left, const asw_image* right, uint8_t* cost,
+                           int disparity_type, int min_disparity, int num_disparity)
+{
+    return cost_ad_common(ctx, left, right, cost, disparity_type, 2, 0, min_disparity, num_disparity);
+}
+
 extern "C" int asw_bgr2gray(asw_ctx* ctx, const asw_image* bgr, uint8_t* gray)
 {
     if (!ctx || !gray) return ASW_ERR_BAD_ARGUMENT;

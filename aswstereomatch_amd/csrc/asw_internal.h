@@ -70,7 +70,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gr
 // cvtColor(COLOR_RGB2GRAY) applied to BGR data, as computeNCC does (M.cpp:835,840): the R and B coefficients swap
 int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray);
 int launch_cost_ad(hipStream_t s, const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type, int minD,
-                   int numD, int do_thresh /* 0: AD, 1: TAD mask */, int threshold, uint8_t* cost);
+                   int numD, int do_thresh /* 0: AD, 1: TAD mask, 2: SD */, int threshold, uint8_t* cost);
 int launch_wta(hipStream_t s, const float* vol, int n, int H, int W, int minD, float* disp);
 
 struct BilateralLaunch {

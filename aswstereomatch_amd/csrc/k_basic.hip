@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t mean3_u8(int c0, int c1, int c2)
     return (uint32_t)((t + c2 + 1) / 3);
 }
 
-// computeAD / computeTAD (M.cpp:208-292, 304-401).  One block per (row, d-slab); the two image
+// computeAD / computeTAD / computeSD (M.cpp:208-292, 304-401, 670-759).  One block per (row, d-slab); the two image
 // rows are staged in LDS once and every disparity plane of the slab is produced from them.
 // Each thread owns 4 consecutive pixels -> one dword store per plane (256 B per wave-instruction).
 template <int C>
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void k_cost_ad(const uint8_t* __restrict__ L, 
                     } else {
                         v = (uint32_t)abs((int)sa[x] - (int)sb[xb]);
                     }
-                    if (do_thresh) v = ((int)v > threshold) ? 255u : 0u;  // compare(CMP_GT) -> 0/255 (App. B-4)
+                    if (do_thresh == 1) v = ((int)v > threshold) ? 255u : 0u;  // compare(CMP_GT) -> 0/255 (App. B-4)
+                    if (do_thresh == 2) v = min(255u, v * v);                  // u8 Mat::mul saturates, M.cpp:701,718
                     packed |= v << (8 * j);
                 }
             }

@@ -167,6 +167,15 @@ inline void computeTAD(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cos
     }, "computeTAD");
 }
 
+// M.h:117-118
+inline void computeSD(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_ds, DisparityType dispType = DISPARITY_LEFT,
+                      int minDisparity = 0, int numDisparity = 30)
+{
+    asw::detail::cost_volume<uint8_t>(leftImg, rightImg, cost_ds, numDisparity, ASW_8U, 0, [&](asw_ctx* c, asw_image* l, asw_image* r, uint8_t* v) {
+        return asw_cost_sd(c, l, r, v, (int)dispType, minDisparity, numDisparity);
+    }, "computeSD");
+}
+
 // M.h:109-111
 inline void computeSimilarity(AswMat leftImg, AswMat rightImg, std::vector<AswMat>& cost_d_imgs, double regularity, double thresC,
                               double thresG, DisparityType dispType, int minDisparity, int numDisparity)

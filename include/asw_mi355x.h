@@ -167,6 +167,9 @@ int asw_cost_ad(asw_ctx* ctx, const asw_image* left, const asw_image* right, uin
 /* computeTAD, M.cpp:304-401: 0/255 mask of AD > threshold_T */
 int asw_cost_tad(asw_ctx* ctx, const asw_image* left, const asw_image* right, uint8_t* cost,
                  int disparity_type, int threshold_t, int min_disparity, int num_disparity);
+/* computeSD, M.h:117-118, M.cpp:670-759: the AD value squared by a u8 Mat::mul, i.e. min(255, ad*ad) */
+int asw_cost_sd(asw_ctx* ctx, const asw_image* left, const asw_image* right, uint8_t* cost,
+                int disparity_type, int min_disparity, int num_disparity);
 /* computeSimilarity (TAD C+G), M.cpp:415-636; win_size = 0 selects the unpadded overload,
  * win_size > 0 the padded one (M.cpp:651-668): planes are (rows+2h) x (cols+2h). */
 int asw_cost_similarity(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost,

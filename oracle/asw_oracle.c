@@ -163,6 +163,19 @@ int orc_compute_tad(const uint8_t* L, const uint8_t* R, int H, int W, int C, int
     return ORC_OK;
 }
 
+/* computeSD, M.cpp:670-759: the AD plane, then color_.mul(color_) on u8 (M.cpp:701,718,735,749) -- OpenCV's 8u multiply
+ * saturates, so every AD >= 16 becomes 255. */
+int orc_compute_sd(const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type, int minD, int numD, uint8_t* cost)
+{
+    int rc = orc_compute_ad(L, R, H, W, C, disp_type, minD, numD, cost);
+    if (rc != ORC_OK) return rc;
+    for (size_t i = 0; i < (size_t)numD * H * W; i++) {
+        const int sq = (int)cost[i] * (int)cost[i];
+        cost[i] = (uint8_t)(sq > 255 ? 255 : sq);
+    }
+    return ORC_OK;
+}
+
 /* filter2D(src 8UC3, CV_32F, Scharr-x char kernel), REFLECT_101, on an image given through an
  * accessor so that the right image can be the REFLECT-padded one.  M.cpp:446-450 (A-7).
  * px(y, c, ch) must be valid for y in [0,H), c in [0,Wimg). */

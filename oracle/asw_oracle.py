@@ -110,6 +110,16 @@ def compute_tad(L, R, disp_type=0, T=30, minD=0, numD=30):
     return rc, out
 
 
+def compute_sd(L, R, disp_type=0, minD=0, numD=30):
+    L, H, W, Cn = _hwc(L)
+    R = np.ascontiguousarray(R, dtype=np.uint8)
+    if L.shape != R.shape:
+        return ERR_SIZE_MISMATCH, None
+    out, po = _out((numD, H, W), np.uint8)
+    rc = lib().orc_compute_sd(L.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p), H, W, Cn, disp_type, minD, numD, po)
+    return rc, out
+
+
 def similarity_pixel(c, g, regularity=0.4, thresC=10.0, thresG=50.0):
     return float(lib().orc_similarity_pixel(int(c[0]), int(c[1]), int(c[2]), float(g[0]), float(g[1]), float(g[2]),
                                             regularity, thresC, thresG))

@@ -27,6 +27,7 @@ def main():
     out["gray_L"] = O.bgr2gray(L)
     out["ad"] = O.compute_ad(L, R, 0, 0, D)[1]
     out["tad"] = O.compute_tad(L, R, 0, 30, 0, D)[1]
+    out["sd"] = O.compute_sd(L, R, 0, 0, D)[1]
     out["similarity"] = O.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1]
     out["sad"] = O.cost_sad(L, R, 0, WIN, 0, D)[1]
     out["geodesic_dist_L"] = O.geodesic_dist(L, WIN, 3)[1]

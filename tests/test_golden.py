@@ -19,6 +19,7 @@ def test_oracle_reproduces_golden(oracle, gold):
     assert np.array_equal(oracle.bgr2gray(L), gold["gray_L"])
     assert np.array_equal(oracle.compute_ad(L, R, 0, 0, D)[1], gold["ad"])
     assert np.array_equal(oracle.compute_tad(L, R, 0, 30, 0, D)[1], gold["tad"])
+    assert np.array_equal(oracle.compute_sd(L, R, 0, 0, D)[1], gold["sd"])
     assert np.array_equal(oracle.compute_similarity(L, R, 0.4, 10, 50, 0, 0, D)[1], gold["similarity"])
     assert np.array_equal(oracle.cost_sad(L, R, 0, WIN, 0, D)[1], gold["sad"])
     assert np.array_equal(oracle.geodesic_dist(L, WIN, 3)[1], gold["geodesic_dist_L"])
@@ -64,6 +65,7 @@ def test_hip_reproduces_golden(gold):
     assert np.array_equal(ctx.bgr2gray(L), gold["gray_L"])
     assert np.array_equal(np.stack(ctx.computeAD(L, R, LEFT, 0, D)), gold["ad"])
     assert np.array_equal(np.stack(ctx.computeTAD(L, R, LEFT, 30, 0, D)), gold["tad"])
+    assert np.array_equal(np.stack(ctx.computeSD(L, R, LEFT, 0, D)), gold["sd"])
     assert np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, LEFT, 0, D)), gold["similarity"])
     assert np.array_equal(np.stack(ctx.getCostSAD(L, R, LEFT, WIN, 0, D)), gold["sad"])
     assert np.array_equal(ctx.getGeodesicDist(L, WIN, 3), gold["geodesic_dist_L"])

@@ -47,6 +47,9 @@ def test_cost_ad_tad(ctx, oracle, H, W, C, dt, minD, numD):
     rc, want = oracle.compute_tad(L, R, dt, 30, minD, numD)
     got = ctx.computeTAD(L, R, dt, 30, minD, numD)
     assert np.array_equal(np.stack(got), want) and set(np.unique(np.stack(got))) <= {0, 255}
+    rc, want = oracle.compute_sd(L // 8, R // 8, dt, minD, numD)  # small differences, so that not every square saturates
+    assert rc == 0 and np.array_equal(np.stack(ctx.computeSD(L // 8, R // 8, dt, minD, numD)), want)
+    assert np.array_equal(np.stack(ctx.computeSD(L, R, dt, minD, numD)), oracle.compute_sd(L, R, dt, minD, numD)[1])
 
 
 def test_cost_ad_reference_error_behaviour(ctx):

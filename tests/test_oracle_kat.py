@@ -42,6 +42,21 @@ def test_k2_tad_is_binary_mask(oracle):
         assert rc == 0 and (cost == want).all()
 
 
+def test_sd_is_saturated_square_of_ad(oracle):
+    # M.cpp:701,735: color_.mul(color_) on a u8 Mat saturates -> 15*15 = 225 is the largest unsaturated value
+    for diffs, want in [((3, 3, 3), 9), ((15, 15, 15), 225), ((16, 16, 16), 255), ((200, 100, 30), 255), ((0, 0, 2), 1)]:
+        L, R = _const_pair(diffs, (0, 0, 0))
+        rc, cost = oracle.compute_sd(L, R, 0, 0, 2)
+        assert rc == 0 and cost.dtype == np.uint8 and (cost == want).all(), (diffs, np.unique(cost))
+    rng = np.random.default_rng(5)
+    for shp in [(9, 14, 3), (9, 14)]:
+        L = rng.integers(0, 40, shp).astype(np.uint8)
+        R = rng.integers(0, 40, shp).astype(np.uint8)
+        for dt in (0, 1):
+            ad = oracle.compute_ad(L, R, dt, 1, 4)[1].astype(int)
+            assert np.array_equal(oracle.compute_sd(L, R, dt, 1, 4)[1], np.minimum(255, ad * ad))
+
+
 def test_ad_reflect_border_and_gray(oracle):
     # LEFT: column x reads R[reflect(x-d)] (BORDER_REFLECT: edge pixel duplicated)  M.cpp:232,237
     L = np.zeros((1, 5), np.uint8)

@@ -96,7 +96,8 @@ def main():
                 rc, vw = O.compute_ad(L, R, dt, minD, numD)
                 rc, tw = O.compute_tad(L, R, dt, 30, minD, numD)
                 ok = (np.array_equal(np.stack(ctx.computeAD(L, R, dt, minD, numD)), vw) and
-                      np.array_equal(np.stack(ctx.computeTAD(L, R, dt, 30, minD, numD)), tw))
+                      np.array_equal(np.stack(ctx.computeTAD(L, R, dt, 30, minD, numD)), tw) and
+                      np.array_equal(np.stack(ctx.computeSD(L // 8, R // 8, dt, minD, numD)), O.compute_sd(L // 8, R // 8, dt, minD, numD)[1]))
             elif method == "similarity":
                 rc, vw = O.compute_similarity(L, R, 0.4, 10, 50, 0, minD, numD)
                 ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, 0, minD, numD)), vw)
