@@ -1,7 +1,9 @@
 // Batch scheduler: frames are independent, so an N-GPU node is used batch-wise --
 // frame i goes to device device_ids[i % n_devices], one host thread + one context per device, no collective
-// and no peer traffic.  Per device the frames are pipelined over two slots: pinned host staging, a copy stream
-// and events overlap the H2D copy of frame n+1 and the D2H copy of frame n-1 with the kernels of frame n.
+// and no peer traffic.  Per device the frames are pipelined over two slots: pinned host staging, one copy stream per
+// direction and events overlap the H2D copy of frame n+1 and the D2H copy of frame n-1 with the kernels of frame n
+// (with a single copy stream the upload of frame n+1 queues behind the download of frame n, i.e. behind its kernels:
+// one bubble of both copies per frame, 12.3 instead of 11.3 ms at 1080p).
 // Contexts, scratch and pinned buffers persist across calls (process lifetime).
 #include <string.h>
 
@@ -42,7 +44,8 @@ void copy_rows(void* dst, size_t dst_step, const void* src, size_t src_step, siz
 // costs far more than a frame, so a batch call reuses the device's context, copy stream and pinned staging.
 struct DeviceState {
     asw_ctx* ctx = nullptr;
-    hipStream_t copy = nullptr;
+    hipStream_t copy = nullptr;  // host -> device
+    hipStream_t back = nullptr;  // device -> host
     Slot slots[2];
     size_t cap_r[2] = {0, 0};
     std::mutex busy;  // one batch worker per DeviceState at a time
@@ -59,7 +62,8 @@ DeviceState* acquire_state(int device, int k)
         if (g_pool_device[i] == device * 1024 + k) return g_pool[i];
     DeviceState* st = new DeviceState();
     if (asw_create(device, &st->ctx) != ASW_OK) { delete st; return nullptr; }
-    bool ok = hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->back, hipStreamNonBlocking) == hipSuccess;
     for (auto& s : st->slots)
         ok = ok && hipEventCreate(&s.up) == hipSuccess && hipEventCreate(&s.done) == hipSuccess && hipEventCreate(&s.down) == hipSuccess;
     if (!ok) { asw_destroy(st->ctx); delete st; return nullptr; }
@@ -75,12 +79,13 @@ int run_device(int device, int k, int n_devices, int n_frames, const asw_image* 
     if (!st) return ASW_ERR_HIP;
     std::lock_guard<std::mutex> lk(st->busy);
     asw_ctx* ctx = st->ctx;
-    hipStream_t copy = st->copy;
+    hipStream_t copy = st->copy, back = st->back;
     Slot* slots = st->slots;
     if (hipSetDevice(device) != hipSuccess) return ASW_ERR_HIP;
     auto fail = [&](int code) {  // leave the device idle and the slots empty, keep the state for the next call
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(copy);
+        (void)hipStreamSynchronize(back);
         slots[0].frame = slots[1].frame = -1;
         return code;
     };
@@ -117,9 +122,9 @@ int run_device(int device, int k, int n_devices, int n_frames, const asw_image* 
             return fail(ASW_ERR_HIP);
         rc = asw_internal_enqueue_match(ctx, n & 1, disparity_type, algorithm, win, minD, numD);
         if (rc != ASW_OK) return fail(rc);
-        if (hipEventRecord(s.done, ctx->stream) != hipSuccess || hipStreamWaitEvent(copy, s.done, 0) != hipSuccess ||
-            hipMemcpyAsync(s.hD, f->disp.p, dsp, hipMemcpyDeviceToHost, copy) != hipSuccess ||
-            hipEventRecord(s.down, copy) != hipSuccess)
+        if (hipEventRecord(s.done, ctx->stream) != hipSuccess || hipStreamWaitEvent(back, s.done, 0) != hipSuccess ||
+            hipMemcpyAsync(s.hD, f->disp.p, dsp, hipMemcpyDeviceToHost, back) != hipSuccess ||
+            hipEventRecord(s.down, back) != hipSuccess)
             return fail(ASW_ERR_HIP);
         s.frame = i;
     }

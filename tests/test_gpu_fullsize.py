@@ -103,6 +103,13 @@ def test_batch_equals_single_frames(ctx):
     for (L, R), o in zip(frames, outs):
         assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7, 0, 24))
     assert asw.stereoMatchingBatch([], [], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) == []
+    # caller-owned output buffers are filled in place
+    mine = [np.full((96, 160), -1.0, np.float32) for _ in frames]
+    got = asw.stereoMatchingBatch([f[0] for f in frames], [f[1] for f in frames], LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 7,
+                                  0, 24, device_ids=[0], out=mine)
+    assert all(g is m for g, m in zip(got, mine)) and all(np.array_equal(m, o) for m, o in zip(mine, outs))
+    with pytest.raises(ValueError):
+        asw.stereoMatchingBatch([frames[0][0]], [frames[0][1]], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8, out=[np.zeros((96, 161), np.float32)])
     # every method of the selector goes through the same scheduler
     for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_BLO1,
                 A.ADAPTIVE_WEIGHT_GUIDED_FILTER, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.ADAPTIVE_WEIGHT_MEDIAN, A.NCC):

@@ -34,3 +34,11 @@ mp = a.width * a.height * a.frames / 1e6
 print("alg %d: sequential %.2f ms/frame (%.1f Mpix/s), pipelined batch %.2f ms/frame (%.1f Mpix/s), identical=%s"
       % (a.alg, t_seq / a.frames * 1e3, mp / t_seq, t_bat / a.frames * 1e3, mp / t_bat, ok))
 ctx.close()
+if os.environ.get("ASW_BATCH_SWEEP"):  # fixed vs per-frame cost of one batch call
+    for n in (1, 2, 4, 8, 16, 32, 32):
+        Ln = [pairs[i % 2][0] for i in range(n)]
+        Rn = [pairs[i % 2][1] for i in range(n)]
+        t = time.perf_counter()
+        asw.stereoMatchingBatch(Ln, Rn, 0, a.alg, 15, 0, a.disp, device_ids=[0])
+        dt = time.perf_counter() - t
+        print("batch of %2d: %.2f ms total, %.2f ms/frame" % (n, dt * 1e3, dt * 1e3 / n))
