@@ -1320,6 +1320,154 @@ int orc_asw_direct8(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int 
 }
 
 /* ---------------------------------------------------------------------------------------
+ * Bilateral-grid ASW: computeAdaptiveWeight_bilateralGrid, M.cpp:2253-2430 (enum 5, called with sampleRateS =
+ * sampleRateR = 10 at M.cpp:67), grid builder createBilGrid M.cpp:1831-2185, quadrlinear_blGrid M.cpp:2227-2251.
+ *
+ * Per candidate offset the reference rebuilds a 4-D grid bilGrid[x][y][zL][zR] of pair<double,int> in nested
+ * std::maps: every pixel adds |gL - gR_shifted| and a count of 1 at its rounded (cvRound = half-to-even) grid key,
+ * four IN-PLACE 5-tap passes (axes zR, zL, y, x, in that order; each pass walks its axis in ascending order and
+ * overwrites as it goes, so taps -1/-2 see already-filtered values; the count is a C int, i.e. every assignment
+ * truncates it) smooth the grid, and a pixel's cost is quadrilinear(first) / quadrilinear(second) over the 16
+ * neighbours at key +-1 around cvCeil(coordinate / rate).  Keys outside the allocated 0..gridSize range are read
+ * through std::map::operator[], which inserts (0.0, 0): reads outside the grid are zeros (App. B, inventory #12).
+ * Here the grid is a dense array with exactly that zero rule.
+ * DISPARITY_RIGHT reads column `width` of the left image (min(x + offset, width), M.cpp:1929,2356: one past the
+ * row) -- undefined behaviour in the reference -> ORC_ERR_UNSUPPORTED_LAYOUT here.
+ * vol (optional): (float)cost, numD+1 planes (NaN where the interpolated count is 0).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    double* f; /* .first  */
+    int* s;    /* .second */
+    int nx, ny, nl, nr; /* gridSize_width/height/rangeL/rangeR: LAST valid index of each axis */
+} blgrid_t;
+
+static inline size_t blg_at(const blgrid_t* g, int x, int y, int l, int r)
+{
+    return (((size_t)x * (size_t)(g->ny + 1) + (size_t)y) * (size_t)(g->nl + 1) + (size_t)l) * (size_t)(g->nr + 1) + (size_t)r;
+}
+static inline int blg_in(const blgrid_t* g, int x, int y, int l, int r)
+{
+    return x >= 0 && x <= g->nx && y >= 0 && y <= g->ny && l >= 0 && l <= g->nl && r >= 0 && r <= g->nr;
+}
+
+/* one line of one smoothing pass, in place, ascending (M.cpp:1936-1993 and its three repetitions) */
+static void blg_pass_line(double* f, int* s, size_t stride, int n)
+{
+#define BF(i) ((i) <= n ? f[(size_t)(i) * stride] : 0.0)
+#define BS(i) ((i) <= n ? (double)s[(size_t)(i) * stride] : 0.0)
+    for (int w = 0; w <= n; w++) {
+        double rf, rs;
+        if (w == 0) {
+            rf = 0.6 * BF(w) + 0.3 * BF(w + 1) + 0.1 * BF(w + 2);
+            rs = 0.6 * BS(w) + 0.3 * BS(w + 1) + 0.1 * BS(w + 2);
+        } else if (w == 1) {
+            rf = 0.2 * BF(w - 1) + 0.5 * BF(w) + 0.2 * BF(w + 1) + 0.1 * BF(w + 2);
+            rs = 0.2 * BS(w - 1) + 0.5 * BS(w) + 0.2 * BS(w + 1) + 0.1 * BS(w + 2);
+        } else if (w == n - 1) {
+            rf = 0.1 * BF(w - 2) + 0.2 * BF(w - 1) + 0.5 * BF(w) + 0.2 * BF(w + 1);
+            rs = 0.1 * BS(w - 2) + 0.2 * BS(w - 1) + 0.5 * BS(w) + 0.2 * BS(w + 1);
+        } else if (w == n) {
+            rf = 0.1 * BF(w - 2) + 0.3 * BF(w - 1) + 0.6 * BF(w);
+            rs = 0.1 * BS(w - 2) + 0.3 * BS(w - 1) + 0.6 * BS(w);
+        } else {
+            rf = 0.0625 * BF(w - 2) + 0.25 * BF(w - 1) + 0.375 * BF(w) + 0.25 * BF(w + 1) + 0.0625 * BF(w + 2);
+            rs = 0.0625 * BS(w - 2) + 0.25 * BS(w - 1) + 0.375 * BS(w) + 0.25 * BS(w + 1) + 0.0625 * BS(w + 2);
+        }
+        f[(size_t)w * stride] = rf;
+        s[(size_t)w * stride] = (int)rs; /* pair<double,double> -> pair<double,int> */
+    }
+#undef BF
+#undef BS
+}
+
+/* quadrlinear_blGrid, M.cpp:2227-2251: d = {x,y,zL,zR} fractions, n[16] with x the slowest and zR the fastest bit */
+static double blg_quadrilinear(const double d[4], const double n[16])
+{
+    double a[8], b[4];
+    for (int i = 0; i < 8; i++) a[i] = n[2 * i] * (1 - d[3]) + n[2 * i + 1] * d[3];
+    for (int i = 0; i < 4; i++) b[i] = a[2 * i] * (1 - d[2]) + a[2 * i + 1] * d[2];
+    const double c1 = b[0] * (1 - d[1]) + b[1] * d[1];
+    const double c2 = b[2] * (1 - d[1]) + b[3] * d[1];
+    return c1 * (1 - d[0]) + c2 * d[0];
+}
+
+static inline int cv_round_d(double v) { return (int)lrint(v); } /* cvRound: to nearest, ties to even */
+static inline int cv_ceil_d(double v) { int i = (int)v; return i + ((double)i < v); }
+
+int orc_asw_bilgrid(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int disp_type, double sampleRateS,
+                    double sampleRateR, int minD, int numD, float* disp, float* vol)
+{
+    if (disp_type != DISPARITY_LEFT) return ORC_ERR_UNSUPPORTED_LAYOUT;
+    if (!(sampleRateS > 0) || !(sampleRateR > 0)) return ORC_ERR_UNSUPPORTED_LAYOUT; /* the slicing divides by them */
+    const int max_offset = minD + numD, min_offset = minD;
+    uint8_t* left = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* right = (uint8_t*)malloc((size_t)H * W);
+    orc_bgr2gray(Lbgr, H, W, left);   /* M.cpp:2271-2278 */
+    orc_bgr2gray(Rbgr, H, W, right);
+    blgrid_t g;
+    g.nl = cv_round_d(255.0 / sampleRateR); /* M.cpp:1868-1871 */
+    g.nr = cv_round_d(255.0 / sampleRateR);
+    g.nx = cv_round_d((W - 1) / sampleRateS);
+    g.ny = cv_round_d((H - 1) / sampleRateS);
+    const size_t cells = (size_t)(g.nx + 1) * (size_t)(g.ny + 1) * (size_t)(g.nl + 1) * (size_t)(g.nr + 1);
+    g.f = (double*)malloc(cells * sizeof(double));
+    g.s = (int*)malloc(cells * sizeof(int));
+    double* best = (double*)malloc((size_t)H * W * sizeof(double));
+    for (size_t i = 0; i < (size_t)H * W; i++) { best[i] = DBL_MAX; disp[i] = 0.0f; } /* never-written pixels: 0 */
+    const size_t sr = 1, sl = (size_t)(g.nr + 1), sy = sl * (size_t)(g.nl + 1), sx = sy * (size_t)(g.ny + 1);
+
+    for (int offset = min_offset; offset <= max_offset; offset++) {
+        memset(g.f, 0, cells * sizeof(double));
+        memset(g.s, 0, cells * sizeof(int));
+        /* grid filling, M.cpp:1897-1915 (sums of integers: exact, any order) */
+        for (int i = 0; i < W; i++)
+            for (int j = 0; j < H; j++) {
+                const float vl = (float)left[(size_t)j * W + i], vr = (float)right[(size_t)j * W + imax(0, i - offset)];
+                const size_t c = blg_at(&g, cv_round_d(i / sampleRateS), cv_round_d(j / sampleRateS),
+                                        cv_round_d(vl / sampleRateR), cv_round_d(vr / sampleRateR));
+                g.f[c] = g.f[c] + fabsf(vl - vr);
+                g.s[c] = g.s[c] + 1;
+            }
+        /* the four passes, in the reference's order: zR, zL, y, x */
+#pragma omp parallel for collapse(2) schedule(static) num_threads(g_threads)
+        for (int x = 0; x <= g.nx; x++)
+            for (int y = 0; y <= g.ny; y++) {
+                for (int l = 0; l <= g.nl; l++) blg_pass_line(g.f + blg_at(&g, x, y, l, 0), g.s + blg_at(&g, x, y, l, 0), sr, g.nr);
+                for (int r = 0; r <= g.nr; r++) blg_pass_line(g.f + blg_at(&g, x, y, 0, r), g.s + blg_at(&g, x, y, 0, r), sl, g.nl);
+            }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int x = 0; x <= g.nx; x++)
+            for (size_t lr = 0; lr < sy; lr++) blg_pass_line(g.f + (size_t)x * sx + lr, g.s + (size_t)x * sx + lr, sy, g.ny);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (long long ylr = 0; ylr < (long long)sx; ylr++) blg_pass_line(g.f + ylr, g.s + ylr, sx, g.nx);
+
+        /* slicing + WTA, M.cpp:2284-2350 */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const double c[4] = {x / sampleRateS, y / sampleRateS, left[(size_t)y * W + x] / sampleRateR,
+                                     right[(size_t)y * W + imax(0, x - offset)] / sampleRateR};
+                int k[4];
+                double d[4];
+                for (int a = 0; a < 4; a++) { k[a] = cv_ceil_d(c[a]); d[a] = k[a] - c[a]; }
+                double nf[16], ns[16];
+                for (int n = 0; n < 16; n++) {
+                    const int gx = k[0] + ((n & 8) ? 1 : -1), gy = k[1] + ((n & 4) ? 1 : -1);
+                    const int gl = k[2] + ((n & 2) ? 1 : -1), gr = k[3] + ((n & 1) ? 1 : -1);
+                    const int in = blg_in(&g, gx, gy, gl, gr);
+                    nf[n] = in ? g.f[blg_at(&g, gx, gy, gl, gr)] : 0.0;
+                    ns[n] = in ? (double)g.s[blg_at(&g, gx, gy, gl, gr)] : 0.0;
+                }
+                const double cur = blg_quadrilinear(d, nf) / blg_quadrilinear(d, ns);
+                if (vol) vol[((size_t)(offset - min_offset) * H + y) * W + x] = (float)cur;
+                if (cur < best[(size_t)y * W + x]) { best[(size_t)y * W + x] = cur; disp[(size_t)y * W + x] = (float)offset; }
+            }
+    }
+    free(left); free(right); free(g.f); free(g.s); free(best);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
  * Driver-side pre/post-processing, aswStereoMatch.cpp ("main.cpp") :30-31, 67-89, 97-98.
  * Five more OpenCV 4.1.0 primitives, restated from their portable C++ paths; none can be verified offline (no OpenCV,
  * no fixture): resize(INTER_LINEAR) on 8UC3 with 11-bit fixed-point coefficients (and its silent switch to INTER_AREA for
@@ -1548,6 +1696,7 @@ int orc_stereo_matching(const uint8_t* L, const uint8_t* R, int H, int W, int di
     case 2: return orc_asw_classic(L, R, H, W, 30, 20, disparity_type, win, minD, numD, disp, NULL);  /* M.cpp:58 */
     case 3: return orc_asw_direct8(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:61 */
     case 4: return orc_asw_geodesic(L, R, H, W, disparity_type, win, minD, numD, disp, NULL);          /* M.cpp:64 */
+    case 5: return orc_asw_bilgrid(L, R, H, W, disparity_type, 10, 10, minD, numD, disp, NULL);        /* M.cpp:67 */
     case 6: return orc_asw_blo1(L, R, H, W, disparity_type, 0.015, win, minD, numD, disp, NULL);       /* M.cpp:70 */
     case 7: return orc_asw_guided(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);      /* M.cpp:73 */
     case 8: return orc_asw_guided2(L, R, H, W, disparity_type, 1e-6, win, minD, numD, disp, NULL);     /* M.cpp:76 */

@@ -202,6 +202,10 @@ def asw_direct8(L, R, disp_type=0, win=15, minD=0, numD=64, want_vol=False):
     return _agg(lib().orc_asw_direct8, L, R, numD + 1, want_vol, disp_type, win, minD, numD)
 
 
+def asw_bilgrid(L, R, disp_type=0, sampleRateS=10.0, sampleRateR=10.0, minD=0, numD=64, want_vol=False):
+    return _agg(lib().orc_asw_bilgrid, L, R, numD + 1, want_vol, disp_type, C.c_double(sampleRateS), C.c_double(sampleRateR), minD, numD)
+
+
 def geodesic_dist(img, win=15, iters=3):
     img, H, W, _ = _hwc(img)
     out, po = _out((H, W, win, win), np.float32)

@@ -535,3 +535,116 @@ def test_f3_disparity_to_u8(oracle):
     d2 = np.array([[10.0, 20.0, 30.0]], np.float32)
     assert oracle.disparity_to_u8(d2).tolist() == [[0, 128, 255]]     # 255/20*10 = 127.5 -> 128 (ties to even)
     assert oracle.disparity_to_u8(np.full((2, 2), 7, np.float32)).tolist() == [[0, 0], [0, 0]]   # max == min -> scale 0
+
+
+def _bilgrid_literal(gl, gr, sS, sR, minD, numD):
+    """computeAdaptiveWeight_bilateralGrid + createBilGrid (M.cpp:1831-2185, 2253-2350) transcribed with the reference's own
+    data structure: nested maps whose operator[] inserts (0.0, 0) for a missing key (a defaultdict does the same)."""
+    from collections import defaultdict
+
+    def rnd(v):  # cvRound: to nearest, ties to even
+        return int(np.rint(v))
+
+    def ceil(v):
+        return int(np.ceil(v))
+
+    H, W = gl.shape
+    best = np.full((H, W), np.finfo(np.float64).max)
+    disp = np.zeros((H, W), np.float32)
+    vol = np.zeros((numD + 1, H, W), np.float32)
+    nr = nl = rnd(255.0 / sR)
+    nx, ny = rnd((W - 1) / sS), rnd((H - 1) / sS)
+
+    def smooth(G, key, n, w):  # one assignment of a pass; key(i) -> grid key at position i of the line
+        g = lambda i: G[key(i)]
+        if w == 0:
+            taps = [(0.6, w), (0.3, w + 1), (0.1, w + 2)]
+        elif w == 1:
+            taps = [(0.2, w - 1), (0.5, w), (0.2, w + 1), (0.1, w + 2)]
+        elif w == n - 1:
+            taps = [(0.1, w - 2), (0.2, w - 1), (0.5, w), (0.2, w + 1)]
+        elif w == n:
+            taps = [(0.1, w - 2), (0.3, w - 1), (0.6, w)]
+        else:
+            taps = [(0.0625, w - 2), (0.25, w - 1), (0.375, w), (0.25, w + 1), (0.0625, w + 2)]
+        f = s = None
+        for c, i in taps:  # left-to-right sums, as the expression is written
+            tf, ts = c * g(i)[0], c * float(g(i)[1])
+            f = tf if f is None else f + tf
+            s = ts if s is None else s + ts
+        G[key(w)] = (f, int(s))  # the count is an int member: truncation
+
+    for k, off in enumerate(range(minD, minD + numD + 1)):
+        G = defaultdict(lambda: (0.0, 0))
+        for i in range(W):
+            for j in range(H):
+                vl, vr = float(gl[j, i]), float(gr[j, max(0, i - off)])
+                key = (rnd(i / sS), rnd(j / sS), rnd(vl / sR), rnd(vr / sR))
+                G[key] = (G[key][0] + abs(vl - vr), G[key][1] + 1)
+        for x in range(nx + 1):
+            for y in range(ny + 1):
+                for z in range(nl + 1):
+                    for w in range(nr + 1):
+                        smooth(G, lambda i: (x, y, z, i), nr, w)
+        for x in range(nx + 1):
+            for y in range(ny + 1):
+                for w in range(nr + 1):
+                    for z in range(nl + 1):
+                        smooth(G, lambda i: (x, y, i, w), nl, z)
+        for w in range(nr + 1):
+            for z in range(nl + 1):
+                for x in range(nx + 1):
+                    for y in range(ny + 1):
+                        smooth(G, lambda i: (x, i, z, w), ny, y)
+        for y in range(ny + 1):
+            for z in range(nl + 1):
+                for w in range(nr + 1):
+                    for x in range(nx + 1):
+                        smooth(G, lambda i: (i, y, z, w), nx, x)
+
+        def quad(d, n):
+            a = [n[2 * i] * (1 - d[3]) + n[2 * i + 1] * d[3] for i in range(8)]
+            b = [a[2 * i] * (1 - d[2]) + a[2 * i + 1] * d[2] for i in range(4)]
+            c1 = b[0] * (1 - d[1]) + b[1] * d[1]
+            c2 = b[2] * (1 - d[1]) + b[3] * d[1]
+            return c1 * (1 - d[0]) + c2 * d[0]
+
+        for y in range(H):
+            for x in range(W):
+                c = [x / sS, y / sS, gl[y, x] / sR, gr[y, max(0, x - off)] / sR]
+                kk = [ceil(v) for v in c]
+                d = [kk[a] - c[a] for a in range(4)]
+                nf, ns = [], []
+                for sx in (-1, 1):
+                    for sy in (-1, 1):
+                        for sl in (-1, 1):
+                            for sr in (-1, 1):
+                                f, s = G[(kk[0] + sx, kk[1] + sy, kk[2] + sl, kk[3] + sr)]
+                                nf.append(f)
+                                ns.append(float(s))
+                with np.errstate(all="ignore"):
+                    cur = np.float64(quad(d, nf)) / np.float64(quad(d, ns))
+                vol[k, y, x] = cur
+                if cur < best[y, x]:
+                    best[y, x] = cur
+                    disp[y, x] = off
+    return disp, vol
+
+
+def test_bilateral_grid_matches_literal_map_restatement(oracle):
+    from aswstereomatch_amd.synth import make_pair
+
+    # coarse range axes on purpose: with fine ones every count is truncated to 0 by the int member and all costs are x/0
+    for (H, W, sS, sR, minD, numD, seed) in [(13, 22, 4.0, 128.0, 0, 3, 1), (20, 30, 6.0, 64.0, 1, 2, 2), (6, 5, 10.0, 10.0, 0, 2, 3),
+                                             (11, 12, 2.5, 100.0, 0, 2, 4), (9, 17, 3.0, 300.0, 0, 2, 5)]:
+        L, R, _ = make_pair(H, W, max(2, numD), seed=seed, block=4)
+        rc, disp, vol = oracle.asw_bilgrid(L, R, 0, sS, sR, minD, numD, want_vol=True)
+        assert rc == 0
+        wd, wv = _bilgrid_literal(oracle.bgr2gray(L), oracle.bgr2gray(R), sS, sR, minD, numD)
+        assert np.array_equal(vol, wv, equal_nan=True), (H, W, sS, sR)
+        assert np.array_equal(disp, wd)
+        assert np.isfinite(vol).mean() > 0.2 or seed > 2
+    # pixels whose coordinate is a multiple of the rate interpolate with weight 1 on key-1: column/row 0 read key -1 -> 0/0
+    assert np.isnan(vol[:, 0, :]).all() and np.isnan(vol[:, :, 0]).all()
+    assert oracle.asw_bilgrid(L, R, 1, 10, 10, 0, 2)[0] != 0      # DISPARITY_RIGHT reads one past the row in the reference
+    assert oracle.asw_bilgrid(L, R, 0, 0, 10, 0, 2)[0] != 0
