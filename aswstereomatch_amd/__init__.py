@@ -210,6 +210,13 @@ class Context:
         return self._aggregate(self._lib.asw_aggregate_blo1, "asw_aggregate_blo1", numDisparity, leftImg, rightImg,
                                (int(dispType), float(sampleRateR), winSize, minDisparity, numDisparity), return_cost_volume)
 
+    def computeAdaptiveWeight_bilateralGrid(self, leftImg, rightImg, dispType=DISPARITY_LEFT, sampleRateS=10, sampleRateR=10,
+                                            minDisparity=186, numDisparity=144, return_cost_volume=False):
+        """M.h:155-157, M.cpp:2253-2430 (DISPARITY_LEFT only: the reference's RIGHT branch reads past the image row)."""
+        return self._aggregate(self._lib.asw_aggregate_bilgrid, "asw_aggregate_bilgrid", numDisparity + 1, leftImg, rightImg,
+                               (int(dispType), float(sampleRateS), float(sampleRateR), minDisparity, numDisparity),
+                               return_cost_volume)
+
     def computeAdaptiveWeight_WeightedMedian(self, leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=35,
                                              sampleRateS=10, sampleRateR=10, minDisparity=186, numDisparity=144,
                                              return_cost_volume=False):

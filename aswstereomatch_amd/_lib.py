@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "asw_stereo_match", "asw_upload_pair", "asw_match_resident", "asw_download_disparity",
     "asw_download_volume", "asw_synchronize", "asw_get_timing",
     "asw_aggregate_bilateral", "asw_aggregate_geodesic", "asw_aggregate_guided", "asw_aggregate_guided2",
-    "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_direct8", "asw_aggregate_guided3",
+    "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_bilgrid", "asw_aggregate_direct8", "asw_aggregate_guided3",
     "asw_cost_ncc", "asw_ncc_disparity",
     "asw_preprocess_pair", "asw_download_pair", "asw_download_disparity_u8",
     "asw_cost_ad", "asw_cost_tad", "asw_cost_sd", "asw_cost_similarity", "asw_cost_sad",
@@ -86,6 +86,7 @@ def lib():
         l.asw_aggregate_guided2.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
         l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P]
         l.asw_aggregate_blo1.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
+        l.asw_aggregate_bilgrid.argtypes = [P, IMG, IMG, IMG, I, D, D, I, I, P]
         l.asw_cost_ad.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_cost_sd.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_cost_tad.argtypes = [P, IMG, IMG, P, I, I, I, I]

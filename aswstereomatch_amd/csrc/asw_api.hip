@@ -359,6 +359,16 @@ extern "C" int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw
     return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BLO1, mp, cost_volume_out);
 }
 
+extern "C" int asw_aggregate_bilgrid(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                                     int disparity_type, double sample_rate_s, double sample_rate_r, int min_disparity,
+                                     int num_disparity, float* cost_volume_out)
+{
+    MatchParams mp;
+    mp.disparity_type = disparity_type; mp.win = 1; mp.minD = min_disparity; mp.numD = num_disparity;
+    mp.grid_rate_s = sample_rate_s; mp.grid_rate_r = sample_rate_r;
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BILATERAL_GRID, mp, cost_volume_out);
+}
+
 extern "C" int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,
                                      int num_disparity, float* cost_volume_out)

@@ -17,6 +17,7 @@ struct MatchParams {
     double eps = 1e-6;                  // M.cpp:73,76
     double rate_s = 10, rate_r = 10;    // M.cpp:82
     double blo_rate_r = 0.015;          // M.cpp:70
+    double grid_rate_s = 10, grid_rate_r = 10;  // M.cpp:67
 };
 
 int check_u8_image(const asw_image* im);

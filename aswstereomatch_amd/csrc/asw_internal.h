@@ -175,6 +175,12 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,
                 int win, int numD, float* vol, float* disp);
 
+// ---- bilateral-grid ASW, k_bilgrid.hip ----
+// grid extents (last index per axis; both range axes share nz); ASW_ERR_BAD_ARGUMENT for rates <= 0 or a range axis too fine for LDS
+int bilgrid_dims(int H, int W, double rate_s, double rate_r, int* nx, int* ny, int* nz);
+int launch_bilgrid(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, double rate_s, double rate_r, int minD,
+                   int numD, double* F, int* S, double* best, float* vol, float* disp);
+
 // ---- hooks for the batch scheduler (batch.hip) ----
 int asw_internal_stage_slot(asw_ctx* ctx, int slot, int rows, int cols, int channels, Frame** out);
 int asw_internal_enqueue_match(asw_ctx* ctx, int slot, int disparity_type, int algorithm, int win_size, int min_disparity,

@@ -501,6 +501,50 @@ static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_vol
     return ASW_OK;
 }
 
+// computeAdaptiveWeight_bilateralGrid, M.cpp:2253-2430.  DISPARITY_LEFT only: the RIGHT branches read column `width` of the
+// left image (min(x + offset, width), M.cpp:1929, 2356), one past the row.
+static int run_bilgrid(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_volume)
+{
+    if (f->channels != 3 && f->channels != 1) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (mp.disparity_type != ASW_DISPARITY_LEFT) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    const int H = f->rows, W = f->cols, n = mp.numD + 1;  // offsets minD .. minD+numD inclusive
+    int nx, ny, nz;
+    ASW_TRY(bilgrid_dims(H, W, mp.grid_rate_s, mp.grid_rate_r, &nx, &ny, &nz));
+    const size_t plane = (size_t)H * W;
+    const size_t cells = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * (nz + 1);
+    if (cells > ((size_t)1 << 33)) return ASW_ERR_ALLOC;  // 8 G cells = 96 GB of grid
+    DevBuf& gl = ctx->buf("grayL");
+    DevBuf& gr = ctx->buf("grayR");
+    DevBuf& gF = ctx->buf("grid_sum");
+    DevBuf& gS = ctx->buf("grid_count");
+    DevBuf& best = ctx->buf("grid_best");
+    ASW_TRY(gl.ensure(plane));
+    ASW_TRY(gr.ensure(plane));
+    ASW_TRY(gF.ensure(cells * 8));
+    ASW_TRY(gS.ensure(cells * 4));
+    ASW_TRY(best.ensure(plane * 8));
+    ASW_TRY(f->disp.ensure(plane * 4));
+    f->vol_floats = 0;
+    if (keep_volume) {
+        ASW_TRY(f->vol.ensure(plane * n * 4));
+        f->vol_floats = plane * n;
+    }
+    if (f->channels == 3) {  // M.cpp:2271-2278
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
+    } else {
+        ASW_HIP_TRY(hipMemcpyAsync(gl.p, f->L.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
+        ASW_HIP_TRY(hipMemcpyAsync(gr.p, f->R.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ASW_TRY(launch_bilgrid(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.grid_rate_s, mp.grid_rate_r, mp.minD, mp.numD,
+                           gF.as<double>(), gS.as<int>(), best.as<double>(), keep_volume ? f->vol.as<float>() : nullptr,
+                           f->disp.as<float>()));
+    ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->timing.aggregate_launches = 1;
+    return ASW_OK;
+}
+
 int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume, bool sync)
 {
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
@@ -511,6 +555,7 @@ int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, boo
     case ASW_ALG_ADAPTIVE_WEIGHT: rc = run_bilateral(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT: rc = run_bilateral(ctx, f, mp, keep_volume, true); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC: rc = run_geodesic(ctx, f, mp, keep_volume); break;
+    case ASW_ALG_ADAPTIVE_WEIGHT_BILATERAL_GRID: rc = run_bilgrid(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_BLO1: rc = run_blo1(ctx, f, mp, keep_volume); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER: rc = run_guided(ctx, f, mp, keep_volume, GUIDED_SAD6); break;
     case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2: rc = run_guided(ctx, f, mp, keep_volume, GUIDED_SIM3); break;

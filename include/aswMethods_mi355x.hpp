@@ -250,6 +250,16 @@ inline AswMat computeAdaptiveWeight_GuidedF_3(AswMat leftImg, AswMat rightImg, D
     }, "computeAdaptiveWeight_GuidedF_3");
 }
 
+// M.h:155-157
+inline AswMat computeAdaptiveWeight_bilateralGrid(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT,
+                                                  double sampleRateS = 10, double sampleRateR = 10, int minDisparity = 186,
+                                                  int numDisparity = 144)
+{
+    return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
+        return asw_aggregate_bilgrid(c, l, r, o, (int)dispType, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr);
+    }, "computeAdaptiveWeight_bilateralGrid");
+}
+
 // M.h:157-159
 inline AswMat computeAdaptiveWeight_BLO1(AswMat leftImg, AswMat rightImg, DisparityType dispType = DISPARITY_LEFT, double sampleRateR = 10,
                                          int winSize = 35, int minDisparity = 186, int numDisparity = 144)

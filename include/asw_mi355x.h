@@ -155,6 +155,13 @@ int asw_aggregate_guided3(asw_ctx* ctx, const asw_image* left, const asw_image* 
 int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                        int disparity_type, double sample_rate_r, int win_size, int min_disparity, int num_disparity,
                        float* cost_volume_out);
+/* computeAdaptiveWeight_bilateralGrid, M.h:155-157, M.cpp:2253-2430 (grid: createBilGrid M.cpp:1831-2185, enum 5 calls it with
+ * rates 10, 10): offsets min_d .. min_d+num_d inclusive, cost volume num_d+1 planes (NaN / inf where the interpolated count is 0).
+ * DISPARITY_LEFT only -- the reference's RIGHT branch reads one column past the row (M.cpp:1929, 2356).
+ * sample_rate_r >= 2.55 (at most 101 bins per range axis). */
+int asw_aggregate_bilgrid(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
+                          int disparity_type, double sample_rate_s, double sample_rate_r, int min_disparity,
+                          int num_disparity, float* cost_volume_out);
 /* computeAdaptiveWeight_WeightedMedian, M.h:179-182, M.cpp:3228-3383 */
 int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,

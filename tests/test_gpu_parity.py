@@ -112,7 +112,7 @@ def test_error_behaviour(ctx):
     assert ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 6, 0, 8) is None and asw.last_status() == asw.ERR_EVEN_WINDOW
     assert ctx.stereoMatching(L, R[:, :30], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8) is None
     assert asw.last_status() == asw.ERR_SIZE_MISMATCH
-    for alg in (A.BM, A.SGBM, A.ADAPTIVE_WEIGHT_BILATERAL_GRID):
+    for alg in (A.BM, A.SGBM):  # OpenCV's own block matchers: not ASW, not rebuilt
         with pytest.raises(asw.AswError) as e:
             ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 8)
         assert e.value.status == asw.ERR_UNSUPPORTED_METHOD
@@ -441,3 +441,44 @@ def test_preprocess_then_match_then_u8(ctx, oracle):
     with pytest.raises(asw.AswError):   # no frame in that slot
         ctx.download_disparity_u8(9, (72, 128))
     assert ctx.preprocess_pair(3, L, R[:, :200], (128, 72)) is False and asw.last_status() == asw.ERR_SIZE_MISMATCH
+
+
+# ---------------------------------------------------------------- bilateral grid (enum 5, inventory #12)
+def _smooth_pair(H, W, d, seed):
+    """Low-texture pair (a few flat regions): grid bins then hold enough pixels for the int counts to survive the smoothing."""
+    rng = np.random.default_rng(seed)
+    base = np.kron(rng.integers(0, 6, (H // 8 + 1, W // 8 + 1)) * 45, np.ones((8, 8), int))[:H, :W]
+    L = np.repeat(base[:, :, None], 3, axis=2).astype(np.uint8)
+    R = np.roll(L, -d, axis=1)
+    return L, R
+
+
+@pytest.mark.parametrize("H,W,sS,sR,minD,numD,smooth", [
+    (40, 64, 10, 10, 0, 6, True), (33, 50, 6, 128, 0, 5, False), (20, 30, 6, 64, 1, 3, False), (6, 5, 10, 10, 0, 2, False),
+    (48, 70, 5.5, 100, 0, 4, False), (17, 200, 7, 33.3, 2, 9, True), (64, 96, 10, 40, 0, 8, False), (9, 9, 3, 300, 0, 12, False),
+    (48, 70, 2.5, 100, 0, 4, False)])
+def test_bilateral_grid_vs_oracle(ctx, oracle, H, W, sS, sR, minD, numD, smooth):
+    L, R = _smooth_pair(H, W, 3, H + W) if smooth else make_pair(H, W, max(2, numD), seed=H * W, block=8)[:2]
+    rc, dw, vw = oracle.asw_bilgrid(L, R, 0, sS, sR, minD, numD, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_bilateralGrid(L, R, LEFT, sS, sR, minD, numD, return_cost_volume=True)
+    assert rc == 0 and v.shape == (numD + 1, H, W)
+    assert np.array_equal(v, vw, equal_nan=True)   # bit-exact: same f64 expression order, integer bin sums
+    assert np.array_equal(d, dw)
+    if sS >= 5 and H >= 17:
+        assert np.isfinite(vw).mean() > 0.3        # not vacuous: a share of the interpolated counts is non-zero
+
+
+def test_bilateral_grid_selector_and_errors(ctx, oracle):
+    L, R = _smooth_pair(40, 64, 2, 5)
+    d = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, 15, 0, 5)   # rates 10, 10 (M.cpp:67)
+    assert np.array_equal(d, oracle.asw_bilgrid(L, R, 0, 10, 10, 0, 5)[1])
+    assert np.array_equal(d, oracle.stereo_matching(L, R, 0, 5, 15, 0, 5)[1])
+    gray = oracle.bgr2gray(L), oracle.bgr2gray(R)
+    assert np.array_equal(ctx.computeAdaptiveWeight_bilateralGrid(gray[0], gray[1], LEFT, 10, 10, 0, 5), d)  # 1-channel input
+    with pytest.raises(asw.AswError) as e:   # the reference's RIGHT branch reads one past the image row
+        ctx.computeAdaptiveWeight_bilateralGrid(L, R, RIGHT, 10, 10, 0, 5)
+    assert e.value.status == asw.ERR_UNSUPPORTED_LAYOUT
+    for rates in ((0, 10), (10, 0), (10, 1.0)):   # division by the rate / more than 101 bins per range axis
+        with pytest.raises(asw.AswError) as e:
+            ctx.computeAdaptiveWeight_bilateralGrid(L, R, LEFT, rates[0], rates[1], 0, 5)
+        assert e.value.status == asw.ERR_BAD_ARGUMENT

@@ -310,7 +310,9 @@ def test_selector_literals(oracle):
     assert rc == 0 and np.array_equal(d, oracle.asw_blo1(L, R, 0, 0.015, 5, 0, 6)[1])
     rc, d = oracle.stereo_matching(L, R, 0, 11, 5, 0, 6)
     assert rc == 0 and np.array_equal(d, oracle.ncc_disparity(L, R, 0, 5, 0, 6)[1])
-    for alg in (0, 1, 5):
+    rc, d = oracle.stereo_matching(L, R, 0, 5, 5, 0, 6)
+    assert rc == 0 and np.array_equal(d, oracle.asw_bilgrid(L, R, 0, 10, 10, 0, 6)[1])
+    for alg in (0, 1):
         assert oracle.stereo_matching(L, R, 0, alg, 5, 0, 6)[0] == oracle.ERR_UNSUPPORTED_METHOD
 
 
