@@ -28,6 +28,7 @@ WORKLOADS = {
     "bilateral": (2, lambda n: n + 1, "classic bilateral ASW (computeAdaptiveWeight)"),
     "direct8": (3, lambda n: n + 1, "direct8 ASW (row + column + diagonal support)"),
     "geodesic": (4, lambda n: n + 1, "geodesic ASW"),
+    "bilgrid": (5, lambda n: n + 1, "bilateral-grid ASW (rates 10, 10)"),
     "blo1": (6, lambda n: n, "O(1)-bilateral ASW (BLO1)"),
     "guided": (7, lambda n: n, "guided-filter ASW (SAD cost, 6-ch guide)"),
     "guided2": (8, lambda n: n, "guided-filter ASW (TAD C+G cost)"),
@@ -89,11 +90,11 @@ def cpu_baseline(args, L, R, gpu_disp, alg):
     # the other methods are not row-local (per-slice normalisation, whole-frame tables): time a smaller frame
     from aswstereomatch_amd.synth import make_pair
 
-    fn = {3: lambda a, b: O.asw_direct8(a, b, 0, win, 0, D), 9: lambda a, b: O.asw_guided3(a, b, 0, 1e-6, win, 0, D),
+    fn = {3: lambda a, b: O.asw_direct8(a, b, 0, win, 0, D), 5: lambda a, b: O.asw_bilgrid(a, b, 0, 10, 10, 0, D), 9: lambda a, b: O.asw_guided3(a, b, 0, 1e-6, win, 0, D),
           11: lambda a, b: O.ncc_disparity(a, b, 0, win, 0, D),
           4: lambda a, b: O.asw_geodesic(a, b, 0, win, 0, D), 6: lambda a, b: O.asw_blo1(a, b, 0, 0.015, win, 0, D), 7: lambda a, b: O.asw_guided(a, b, 0, 1e-6, win, 0, D),
           8: lambda a, b: O.asw_guided2(a, b, 0, 1e-6, win, 0, D), 10: lambda a, b: O.asw_wmedian(a, b, 0, win, 10, 10, 0, D)}[alg]
-    sw, sh = {3: (1280, 720), 9: (640, 360), 11: (640, 360), 4: (1242, 375), 6: (480, 270), 7: (1280, 720), 8: (1920, 1080), 10: (621, 188)}[alg]  # sized for ~3-10 s on 16 cores
+    sw, sh = {3: (1280, 720), 5: (640, 360), 9: (640, 360), 11: (640, 360), 4: (1242, 375), 6: (480, 270), 7: (1280, 720), 8: (1920, 1080), 10: (621, 188)}[alg]  # sized for ~3-10 s on 16 cores
     sw, sh = min(sw, W), min(sh, H)
     Ls, Rs, _ = make_pair(sh, sw, min(D, sw // 2), seed=4321)
     t = time.time()

@@ -42,6 +42,7 @@ def main():
                      ("guided2", lambda: O.asw_guided2(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("wmedian", lambda: O.asw_wmedian(L, R, 0, WIN, 10, 10, 0, D, want_vol=True)),
                      ("blo1", lambda: O.asw_blo1(L, R, 0, 0.015, WIN, 0, D, want_vol=True)),
+                     ("bilgrid", lambda: O.asw_bilgrid((L // 64) * 64, (R // 64) * 64, 0, 6, 64, 0, D, want_vol=True)),
                      ("direct8", lambda: O.asw_direct8(L, R, 0, WIN, 0, D, want_vol=True)),
                      ("guided3", lambda: O.asw_guided3(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided3_right", lambda: O.asw_guided3(L, R, 1, 1e-6, WIN, 0, D, want_vol=True)),

@@ -31,6 +31,7 @@ def test_oracle_reproduces_golden(oracle, gold):
     assert np.array_equal(oracle.ncc_disparity(L, R, 0, WIN, 0, D)[1], gold["ncc_disp"])
     for name, fn in [("classic", lambda: oracle.asw_classic(L, R, 30, 20, 0, WIN, 0, D, want_vol=True)),
                      ("direct8", lambda: oracle.asw_direct8(L, R, 0, WIN, 0, D, want_vol=True)),
+                     ("bilgrid", lambda: oracle.asw_bilgrid((L // 64) * 64, (R // 64) * 64, 0, 6, 64, 0, D, want_vol=True)),
                      ("guided3", lambda: oracle.asw_guided3(L, R, 0, 1e-6, WIN, 0, D, want_vol=True)),
                      ("guided3_right", lambda: oracle.asw_guided3(L, R, 1, 1e-6, WIN, 0, D, want_vol=True)),
                      ("geodesic", lambda: oracle.asw_geodesic(L, R, 0, WIN, 0, D, want_vol=True)),
@@ -102,4 +103,7 @@ def test_hip_reproduces_golden(gold):
     gv = gold["blo1_vol"]
     fin = np.isfinite(gv)
     assert np.array_equal(d, gold["blo1_disp"]) and np.allclose(v[fin], gv[fin], rtol=1e-4, atol=0)
+    d, v = ctx.computeAdaptiveWeight_bilateralGrid((L // 64) * 64, (R // 64) * 64, LEFT, 6, 64, 0, D, return_cost_volume=True)
+    assert np.array_equal(d, gold["bilgrid_disp"]) and np.array_equal(v, gold["bilgrid_vol"], equal_nan=True)
+    assert np.isfinite(gold["bilgrid_vol"]).mean() > 0.3
     ctx.close()

@@ -111,7 +111,7 @@ def test_batch_equals_single_frames(ctx):
     with pytest.raises(ValueError):
         asw.stereoMatchingBatch([frames[0][0]], [frames[0][1]], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 8, out=[np.zeros((96, 161), np.float32)])
     # every method of the selector goes through the same scheduler
-    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_BLO1,
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_8DIRECT, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, A.ADAPTIVE_WEIGHT_BLO1,
                 A.ADAPTIVE_WEIGHT_GUIDED_FILTER, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_3, A.ADAPTIVE_WEIGHT_MEDIAN, A.NCC):
         outs = asw.stereoMatchingBatch([f[0] for f in frames[:3]], [f[1] for f in frames[:3]], LEFT, alg, 7, 0, 12, device_ids=[0, 0])
         for (L, R), o in zip(frames[:3], outs):

@@ -50,7 +50,7 @@ def main():
         seed = int(rng.integers(0, 1 << 30))
         L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
-                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep"]))
+                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
         try:
             if method == "classic":
@@ -79,6 +79,16 @@ def main():
                 d, v = ctx.computeAdaptiveWeight_GuidedF_3(L, R, dt, 1e-6, win, minD, numD, return_cost_volume=True)
                 # flat windows make NaN costs: their WTA is build-defined on both sides, compare where finite
                 ok = close(v, vw) and np.array_equal(d[np.isfinite(vw).all(axis=0)], dw[np.isfinite(vw).all(axis=0)])
+            elif method == "bilgrid":
+                sS = float(rng.choice([2.5, 4, 6, 7.5, 10, 16]))
+                sR = float(rng.choice([10, 33.3, 40, 64, 128, 300]))
+                if rng.integers(0, 2):  # flat regions: bins with enough pixels for the int counts to survive
+                    L = (L // 64) * 64
+                    R = (R // 64) * 64
+                nD = min(numD, 12)
+                rc, dw, vw = O.asw_bilgrid(L, R, 0, sS, sR, minD, nD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_bilateralGrid(L, R, 0, sS, sR, minD, nD, return_cost_volume=True)
+                ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
             elif method == "wmedian":
                 win = min(win, 17)
                 rc, dw, vw = O.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)

@@ -39,6 +39,7 @@ bench blo1 --workload blo1 --frames 2 --steps 2
 bench direct8 --workload direct8 --frames 8 --steps 3
 bench guided3 --workload guided3 --frames 2 --steps 2
 bench ncc --workload ncc --frames 4 --steps 3
+bench bilgrid --workload bilgrid --frames 2 --steps 2
 
 # the rocprofv3 summary of the SAME command as the headline bench line (CPU baseline skipped: it is host-only work)
 stats bilateral_bench "$ROOT/bench.py" --no-cpu
@@ -50,6 +51,7 @@ stats alg6 "$ROOT/tools/run_one.py" --alg 6 --reps 2
 stats alg3 "$ROOT/tools/run_one.py" --alg 3 --reps 3
 stats alg9 "$ROOT/tools/run_one.py" --alg 9 --reps 2
 stats alg11 "$ROOT/tools/run_one.py" --alg 11 --reps 3
+stats alg5 "$ROOT/tools/run_one.py" --alg 5 --reps 2
 
 pmc bilateral_FETCH_SIZE "FETCH_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc bilateral_WRITE_SIZE "WRITE_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
