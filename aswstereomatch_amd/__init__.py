@@ -292,6 +292,19 @@ class Context:
         self._finish(rc, "asw_wta")
         return disp
 
+    def leftRightCheck(self, dispLeft, dispRight, maxDiff=1.0, invalid=-1.0):
+        """asw_lr_check: (checked left disparity, number of rejected pixels)."""
+        a = np.ascontiguousarray(dispLeft, dtype=np.float32)
+        b = np.ascontiguousarray(dispRight, dtype=np.float32)
+        if a.ndim != 2 or a.shape != b.shape:
+            raise ValueError("leftRightCheck: two float32 maps of equal (H, W) shape expected")
+        out = np.zeros(a.shape, np.float32)
+        n = C.c_int(0)
+        rc = self._lib.asw_lr_check(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1],
+                                    float(maxDiff), float(invalid), out.ctypes.data_as(C.c_void_p), C.byref(n))
+        self._finish(rc, "asw_lr_check")
+        return out, n.value
+
     def bgr2gray(self, img):
         ii, ia = _image(img)
         out = np.zeros(ia.shape[:2], np.uint8)

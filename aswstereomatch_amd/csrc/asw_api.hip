@@ -132,6 +132,30 @@ extern "C" int asw_wta(asw_ctx* ctx, const float* cost_volume, int n, int rows, 
     return ASW_OK;
 }
 
+extern "C" int asw_lr_check(asw_ctx* ctx, const float* disp_left, const float* disp_right, int rows, int cols, float max_diff,
+                            float invalid_value, float* out, int* n_invalid)
+{
+    if (!ctx || !disp_left || !disp_right || !out || rows <= 0 || cols <= 0 || !(max_diff >= 0)) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t plane = (size_t)rows * cols;
+    DevBuf& a = ctx->buf("lr_left");
+    DevBuf& b = ctx->buf("lr_right");
+    DevBuf& o = ctx->buf("lr_out");
+    DevBuf& c = ctx->buf("lr_count");
+    ASW_TRY(a.ensure(plane * 4));
+    ASW_TRY(b.ensure(plane * 4));
+    ASW_TRY(o.ensure(plane * 4));
+    ASW_TRY(c.ensure(sizeof(unsigned)));
+    ASW_HIP_TRY(hipMemcpyAsync(a.p, disp_left, plane * 4, hipMemcpyHostToDevice, ctx->stream));
+    ASW_HIP_TRY(hipMemcpyAsync(b.p, disp_right, plane * 4, hipMemcpyHostToDevice, ctx->stream));
+    ASW_TRY(launch_lr_check(ctx->stream, a.as<float>(), b.as<float>(), rows, cols, max_diff, invalid_value, o.as<float>(), c.as<unsigned>()));
+    unsigned bad = 0;
+    ASW_HIP_TRY(hipMemcpyAsync(out, o.p, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipMemcpyAsync(&bad, c.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_invalid) *n_invalid = (int)bad;
+    return ASW_OK;
+}
 
 extern "C" int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                     int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,

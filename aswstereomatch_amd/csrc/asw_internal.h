@@ -175,6 +175,9 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,
                 int win, int numD, float* vol, float* disp);
 
+int launch_lr_check(hipStream_t s, const float* dl, const float* dr, int H, int W, float max_diff, float invalid, float* out,
+                    unsigned* n_invalid);
+
 // ---- bilateral-grid ASW, k_bilgrid.hip ----
 // grid extents (last index per axis; both range axes share nz); ASW_ERR_BAD_ARGUMENT for rates <= 0 or a range axis too fine for LDS
 int bilgrid_dims(int H, int W, double rate_s, double rate_r, int* nx, int* ny, int* nz);

@@ -166,6 +166,32 @@ int launch_cost_ad(hipStream_t s, const uint8_t* L, const uint8_t* R, int H, int
     return ASW_OK;
 }
 
+// Left-right consistency check (the consumer of the DISPARITY_RIGHT maps; the reference has none, so the rule
+// is this build's: a left pixel x with disparity d points at right pixel x - d, whose own disparity must agree within max_diff).
+__global__ __launch_bounds__(256) void k_lr_check(const float* __restrict__ dl, const float* __restrict__ dr, int H, int W,
+                                                  float max_diff, float invalid, float* __restrict__ out, unsigned* __restrict__ n_invalid)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool bad = false;
+    if (x < W && y < H) {
+        const float d = dl[(size_t)y * W + x];
+        const int xr = x - (int)d;
+        bad = !(xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + min(max(xr, 0), W - 1)]) <= max_diff);  // NaN fails too
+        out[(size_t)y * W + x] = bad ? invalid : d;
+    }
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_invalid, (unsigned)__popcll(m));
+}
+
+int launch_lr_check(hipStream_t s, const float* dl, const float* dr, int H, int W, float max_diff, float invalid, float* out,
+                    unsigned* n_invalid)
+{
+    ASW_HIP_TRY(hipMemsetAsync(n_invalid, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_lr_check, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, dl, dr, H, W, max_diff, invalid, out, n_invalid);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
 int launch_wta(hipStream_t s, const float* vol, int n, int H, int W, int minD, float* disp)
 {
     size_t plane = (size_t)H * W;

@@ -269,6 +269,20 @@ inline AswMat computeAdaptiveWeight_BLO1(AswMat leftImg, AswMat rightImg, Dispar
     }, "computeAdaptiveWeight_BLO1");
 }
 
+// Not in the reference: the cross-check that consumes a DISPARITY_LEFT and a DISPARITY_RIGHT map (asw_lr_check)
+inline AswMat leftRightCheck(AswMat dispLeft, AswMat dispRight, float maxDiff = 1.0f, float invalidValue = -1.0f, int* nInvalid = nullptr)
+{
+    if (dispLeft.rows != dispRight.rows || dispLeft.cols != dispRight.cols) return AswMat();
+    AswMat out = asw::detail::make(dispLeft.rows, dispLeft.cols, ASW_32F, 1);
+    asw_image a = asw::detail::view(dispLeft), b = asw::detail::view(dispRight), o = asw::detail::view(out);
+    if (a.depth != ASW_32F || b.depth != ASW_32F || a.step != (size_t)a.cols * 4 || b.step != (size_t)b.cols * 4 || o.step != (size_t)o.cols * 4)
+        throw std::runtime_error("leftRightCheck: continuous CV_32FC1 maps expected");
+    int rc = asw_lr_check(asw::detail::context(), (const float*)a.data, (const float*)b.data, a.rows, a.cols, maxDiff, invalidValue,
+                          (float*)o.data, nInvalid);
+    asw::detail::raise_unless_ok(rc, "leftRightCheck");
+    return rc == ASW_OK ? out : AswMat();
+}
+
 // M.h:165
 inline AswMat getGuidedFilter(AswMat guidedImg, AswMat inputP, int r, double eps)
 {

@@ -204,6 +204,11 @@ int asw_geodesic_dist(asw_ctx* ctx, const asw_image* img, float* out, int win_si
 /* inline WTA of M.cpp:1144-1150 / 3032-3048 on a dense f32 volume [n][rows][cols] */
 int asw_wta(asw_ctx* ctx, const float* cost_volume, int n, int rows, int cols, int min_disparity,
             float* disp);
+/* Left-right consistency check, the consumer of the DISPARITY_RIGHT maps (M.cpp:1113-1142, 1498-1520, 2919-2935 produce them;
+ * the reference itself never cross-checks, so the rule is this library's): out(y,x) = dl(y,x) if xr = x - (int)dl(y,x) lies in
+ * [0, cols) and |dl(y,x) - dr(y,xr)| <= max_diff, else invalid_value.  n_invalid (optional) receives the number of rejected pixels. */
+int asw_lr_check(asw_ctx* ctx, const float* disp_left, const float* disp_right, int rows, int cols, float max_diff,
+                 float invalid_value, float* out, int* n_invalid);
 /* cvtColor(COLOR_BGR2GRAY) as used at M.cpp:1031-1033 */
 int asw_bgr2gray(asw_ctx* ctx, const asw_image* bgr, uint8_t* gray);
 

@@ -1319,6 +1319,22 @@ int orc_asw_direct8(const uint8_t* Lbgr, const uint8_t* Rbgr, int H, int W, int 
     return ORC_OK;
 }
 
+/* Left-right consistency check (the build's own rule, include/asw_mi355x.h asw_lr_check; the reference has no such step):
+ * keep dl(y,x) when the right map agrees at x - (int)dl within max_diff, else `invalid`.  Returns the number rejected. */
+int orc_lr_check(const float* dl, const float* dr, int H, int W, float max_diff, float invalid, float* out)
+{
+    int bad = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float d = dl[(size_t)y * W + x];
+            const int xr = x - (int)d;
+            const int ok = xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + (xr < 0 ? 0 : xr >= W ? W - 1 : xr)]) <= max_diff;
+            out[(size_t)y * W + x] = ok ? d : invalid;
+            bad += !ok;
+        }
+    return bad;
+}
+
 /* ---------------------------------------------------------------------------------------
  * Bilateral-grid ASW: computeAdaptiveWeight_bilateralGrid, M.cpp:2253-2430 (enum 5, called with sampleRateS =
  * sampleRateR = 10 at M.cpp:67), grid builder createBilGrid M.cpp:1831-2185, quadrlinear_blGrid M.cpp:2227-2251.

@@ -167,6 +167,14 @@ def wta(volume, minD=0):
     return out
 
 
+def lr_check(dl, dr, max_diff=1.0, invalid=-1.0):
+    dl, pl = _f32(dl)
+    dr, pr = _f32(dr)
+    out, po = _out(dl.shape, np.float32)
+    bad = lib().orc_lr_check(pl, pr, dl.shape[0], dl.shape[1], C.c_float(max_diff), C.c_float(invalid), po)
+    return out, bad
+
+
 def classic_taps(ks):
     nt = ks * ks - 1
     arrs = [np.zeros(nt, dtype=np.int32) for _ in range(4)]

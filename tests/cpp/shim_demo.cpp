@@ -3,6 +3,7 @@
 // Reads two 8UC3 images, calls stereoMatching() exactly like aswStereoMatch.cpp:94 does, writes the f32 map.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "aswMethods_mi355x.hpp"
 
@@ -25,7 +26,14 @@ int main(int argc, char** argv)
     if (disp.empty()) { printf("empty\n"); return 0; }
     std::vector<AswMat> ad;
     computeAD(L, R, ad, DISPARITY_LEFT, minD, 4);
-    printf("ok %d %d planes=%zu\n", disp.rows, disp.cols, ad.size());
+    std::vector<AswMat> sd;
+    computeSD(L, R, sd, DISPARITY_LEFT, minD, 3);  // M.h:117-118
+    int same = -1;
+    if (alg == ADAPTIVE_WEIGHT_BILATERAL_GRID) {   // the per-method function with the selector's literals (M.cpp:67)
+        AswMat g = computeAdaptiveWeight_bilateralGrid(L, R, DISPARITY_LEFT, 10, 10, minD, numD);
+        same = !g.empty() && memcmp(g.data, disp.data, (size_t)H * W * 4) == 0;
+    }
+    printf("ok %d %d planes=%zu sd=%zu same=%d\n", disp.rows, disp.cols, ad.size(), sd.size(), same);
     FILE* f = fopen(argv[9], "wb");
     fwrite(disp.data, 1, (size_t)H * W * 4, f);
     fclose(f);

@@ -75,11 +75,11 @@ def test_shim_matches_ctypes_path(tmp_path):
     L.tofile(tmp_path / "l.raw")
     R.tofile(tmp_path / "r.raw")
     ctx = asw.Context(0)
-    for alg in (2, 8):
+    for alg in (2, 8, 5):
         out = tmp_path / ("d%d.raw" % alg)
         r = subprocess.run([EXE, "40", "72", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(alg), "7", "0", "10", str(out)],
                            capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0 and r.stdout.startswith("ok 40 72 planes=4"), (r.stdout, r.stderr)
+        assert r.returncode == 0 and r.stdout.startswith("ok 40 72 planes=4 sd=3 same=%d" % (1 if alg == 5 else -1)), (r.stdout, r.stderr)
         got = np.fromfile(out, np.float32).reshape(40, 72)
         assert np.array_equal(got, ctx.stereoMatching(L, R, asw.DISPARITY_LEFT, alg, 7, 0, 10))
     # even window: the reference returns an empty Mat (M.cpp:1440-1443) -> so does the shim

@@ -482,3 +482,25 @@ def test_bilateral_grid_selector_and_errors(ctx, oracle):
         with pytest.raises(asw.AswError) as e:
             ctx.computeAdaptiveWeight_bilateralGrid(L, R, LEFT, rates[0], rates[1], 0, 5)
         assert e.value.status == asw.ERR_BAD_ARGUMENT
+
+
+# ---------------------------------------------------------------- left-right check (consumer of the RIGHT maps)
+def test_left_right_check(ctx, oracle):
+    L, R, gt = make_pair(60, 120, 12, seed=21)
+    dl = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 9, 0, 12)
+    dr = ctx.stereoMatching(L, R, RIGHT, A.ADAPTIVE_WEIGHT, 9, 0, 12)
+    for tau, inv in ((1.0, -1.0), (0.0, 0.0), (3.0, np.float32(np.nan))):
+        got, bad = ctx.leftRightCheck(dl, dr, tau, inv)
+        want, wbad = oracle.lr_check(dl, dr, tau, inv)
+        assert np.array_equal(got, want, equal_nan=True) and bad == wbad
+    got, bad = ctx.leftRightCheck(dl, dr, 1.0, -1.0)
+    kept = got >= 0
+    assert 0.5 < kept.mean() < 1.0                      # occlusions and border columns are rejected, the bulk survives
+    assert (np.abs(got[kept] - gt[kept]) <= 1).mean() > 0.9   # and what survives is mostly right
+    # NaN / out-of-image targets
+    a = np.array([[np.nan, 5.0, 1.0, 0.0]], np.float32)
+    b = np.array([[0.0, 9.0, 9.0, 0.0]], np.float32)
+    got, bad = ctx.leftRightCheck(a, b, 1.0, -2.0)
+    assert np.array_equal(got, [[-2.0, -2.0, -2.0, 0.0]]) and bad == 3
+    with pytest.raises(asw.AswError):
+        ctx.leftRightCheck(a, b, -1.0)

@@ -650,3 +650,25 @@ def test_bilateral_grid_matches_literal_map_restatement(oracle):
     assert np.isnan(vol[:, 0, :]).all() and np.isnan(vol[:, :, 0]).all()
     assert oracle.asw_bilgrid(L, R, 1, 10, 10, 0, 2)[0] != 0      # DISPARITY_RIGHT reads one past the row in the reference
     assert oracle.asw_bilgrid(L, R, 0, 0, 10, 0, 2)[0] != 0
+
+
+def test_lr_check_rule(oracle):
+    rng = np.random.default_rng(3)
+    dl = rng.integers(0, 9, (7, 20)).astype(np.float32)
+    dr = rng.integers(0, 9, (7, 20)).astype(np.float32)
+    dl[0, 0] = np.nan
+    for tau in (0.0, 1.0, 2.5):
+        out, bad = oracle.lr_check(dl, dr, tau, -7.0)
+        want = np.full(dl.shape, -7.0, np.float32)
+        for y in range(7):
+            for x in range(20):
+                d = dl[y, x]
+                if not np.isnan(d):
+                    xr = x - int(d)
+                    if 0 <= xr < 20 and abs(d - dr[y, xr]) <= tau:
+                        want[y, x] = d
+        assert np.array_equal(out, want) and bad == int((want == -7.0).sum())
+    # a consistent pair (right map = left map resampled) keeps everything that stays inside the image
+    d = np.full((3, 10), 2.0, np.float32)
+    out, bad = oracle.lr_check(d, d, 0.0, -1.0)
+    assert bad == 6 and (out[:, :2] == -1).all() and (out[:, 2:] == 2).all()
