@@ -143,3 +143,43 @@ def test_large_windows(ctx, oracle, win):
     assert rc == 0 and np.allclose(v[fin], vw[fin], rtol=1e-4, atol=0) and np.array_equal(d, dw)
     rc, ww = oracle.geodesic_dist(L[:20, :30], win, 3)
     assert np.array_equal(ctx.getGeodesicDist(L[:20, :30], win, 3), ww)
+
+
+def test_one_context_per_thread_runs_concurrently(ctx):
+    """SURVEY 8b threading: one ctx per thread, never shared.  Four host threads, each with its own context and its own
+    method, interleave on the device; every result equals the single-threaded one."""
+    import threading
+
+    L, R, _ = make_pair(72, 160, 16, seed=33)
+    algs = [A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_GEODESIC, A.ADAPTIVE_WEIGHT_BILATERAL_GRID]
+    want = [ctx.stereoMatching(L, R, LEFT, a, 9, 0, 16) for a in algs]
+    got = [None] * len(algs)
+    errs = []
+
+    def work(i):
+        try:
+            c = asw.Context(0)
+            for _ in range(3):
+                got[i] = c.stereoMatching(L, R, LEFT, algs[i], 9, 0, 16)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(algs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_batch_on_a_missing_device_fails_cleanly():
+    L, R, _ = make_pair(16, 32, 4, seed=2)
+    with pytest.raises(asw.AswError) as e:
+        asw.stereoMatchingBatch([L], [R], LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4, device_ids=[99])
+    assert e.value.status in (asw.ERR_HIP, asw.ERR_BAD_ARGUMENT)
+    # and the scheduler still works afterwards
+    out = asw.stereoMatchingBatch([L], [R], LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4, device_ids=[0])
+    assert out[0].shape == (16, 32)

@@ -456,7 +456,8 @@ def _smooth_pair(H, W, d, seed):
 @pytest.mark.parametrize("H,W,sS,sR,minD,numD,smooth", [
     (40, 64, 10, 10, 0, 6, True), (33, 50, 6, 128, 0, 5, False), (20, 30, 6, 64, 1, 3, False), (6, 5, 10, 10, 0, 2, False),
     (48, 70, 5.5, 100, 0, 4, False), (17, 200, 7, 33.3, 2, 9, True), (64, 96, 10, 40, 0, 8, False), (9, 9, 3, 300, 0, 12, False),
-    (48, 70, 2.5, 100, 0, 4, False)])
+    (48, 70, 2.5, 100, 0, 4, False),
+    (33, 50, 12, 6.5, 1, 3, True), (48, 80, 16, 4.0, 0, 3, True), (21, 33, 8, 3.0, 1, 3, True)])   # > 36 bins per range axis: the slicing gathers from global memory
 def test_bilateral_grid_vs_oracle(ctx, oracle, H, W, sS, sR, minD, numD, smooth):
     L, R = _smooth_pair(H, W, 3, H + W) if smooth else make_pair(H, W, max(2, numD), seed=H * W, block=8)[:2]
     rc, dw, vw = oracle.asw_bilgrid(L, R, 0, sS, sR, minD, numD, want_vol=True)
@@ -464,7 +465,7 @@ def test_bilateral_grid_vs_oracle(ctx, oracle, H, W, sS, sR, minD, numD, smooth)
     assert rc == 0 and v.shape == (numD + 1, H, W)
     assert np.array_equal(v, vw, equal_nan=True)   # bit-exact: same f64 expression order, integer bin sums
     assert np.array_equal(d, dw)
-    if sS >= 5 and H >= 17:
+    if sS >= 5 and H >= 17 and sR > 3:
         assert np.isfinite(vw).mean() > 0.3        # not vacuous: a share of the interpolated counts is non-zero
 
 

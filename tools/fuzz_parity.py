@@ -81,7 +81,7 @@ def main():
                 ok = close(v, vw) and np.array_equal(d[np.isfinite(vw).all(axis=0)], dw[np.isfinite(vw).all(axis=0)])
             elif method == "bilgrid":
                 sS = float(rng.choice([2.5, 4, 6, 7.5, 10, 16]))
-                sR = float(rng.choice([10, 33.3, 40, 64, 128, 300]))
+                sR = float(rng.choice([3, 5, 10, 33.3, 40, 64, 128, 300]))
                 if rng.integers(0, 2):  # flat regions: bins with enough pixels for the int counts to survive
                     L = (L // 64) * 64
                     R = (R // 64) * 64
