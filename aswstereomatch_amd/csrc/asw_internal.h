@@ -107,8 +107,7 @@ int launch_u8_scale(hipStream_t s, const uint8_t* img, size_t nbytes, uint32_t* 
 int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t* shifted_img, int H, int W, int minD, int numD,
                            int disp_type, uint32_t* ord_scratch, int* colmm_scratch /* 2W */, float2* scales /* numD */);
 
-// ---- box means / guided filter (k_guided.hip) ----
-// ---- NCC cost (k_ncc.hip), computeNCC / getInputImgNCC, M.cpp:767-1013 ----
+// ---- NCC cost (k_ncc.hip), computeNCC / getInputImgNCC, M.cpp:767-1013; launch_box_mean_u8 lives in k_guided.hip ----
 struct NccLaunch {
     const uint8_t* gref;  // reference gray image [H][W]
     const float* mref;    // its box means
@@ -133,6 +132,7 @@ int launch_boost_hsv2bgr(hipStream_t s, const uint8_t* hsv, int H, int W, const 
                          uint8_t* bgr);
 int launch_disp_to_u8(hipStream_t s, const float* disp, size_t n, int normalize, uint8_t* out, int* mm_scratch);
 
+// ---- box means / guided filter (k_guided.hip) ----
 int launch_cost_sad(hipStream_t s, const uint8_t* gl, const uint8_t* gr, int H, int W, int disp_type, int win, int minD,
                     int numD, float* cost);
 struct GuidedLaunch {
@@ -171,7 +171,7 @@ int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, 
 int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
                    int max_off, float* out);
 
-// ---- O(1)-bilateral ASW (BLO1), k_guided.hip ----
+// ---- O(1)-bilateral ASW (BLO1), k_blo1.hip ----
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,
                 int win, int numD, float* vol, float* disp);
 
