@@ -97,12 +97,15 @@ __global__ __launch_bounds__(256) void k_cost_ad(const uint8_t* __restrict__ L, 
 
 // WTA (M.cpp:1144-1150, 3032-3048): strict '<' in ascending d against DBL_MAX, NaN never wins,
 // never-updated pixels are 0 (build-defined; the reference leaves them uninitialised, App. B-16).
+// VEC pixels per thread: 4 (one dwordx4 per plane) for large planes, 1 for planes too small to fill the chip with a quarter
+// of a thread per pixel (640x360: 225 workgroups at VEC = 4).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, int n, size_t plane, int minD,
                                              float* __restrict__ disp)
 {
-    size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i4 >= plane) return;
-    if (i4 + 3 < plane && (plane & 3) == 0) {
+    if (VEC == 4 && i4 + 3 < plane && (plane & 3) == 0) {
         float best[4] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
         bool any[4] = {false, false, false, false};
         float bd[4] = {0, 0, 0, 0};
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, int 
         }
         *reinterpret_cast<float4*>(disp + i4) = make_float4(bd[0], bd[1], bd[2], bd[3]);
     } else {
-        for (size_t i = i4; i < plane && i < i4 + 4; i++) {
+        for (size_t i = i4; i < plane && i < i4 + VEC; i++) {
             double best = 1.7976931348623157e308;
             float bd = 0.0f;
             for (int k = 0; k < n; k++) {
@@ -195,8 +198,12 @@ int launch_lr_check(hipStream_t s, const float* dl, const float* dr, int H, int 
 int launch_wta(hipStream_t s, const float* vol, int n, int H, int W, int minD, float* disp)
 {
     size_t plane = (size_t)H * W;
-    int blocks = (int)((plane / 4 + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_wta, dim3(blocks), dim3(256), 0, s, vol, n, plane, minD, disp);
+    if (plane < ((size_t)1 << 20)) {
+        hipLaunchKernelGGL(k_wta<1>, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, vol, n, plane, minD, disp);
+    } else {
+        int blocks = (int)((plane / 4 + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_wta<4>, dim3(blocks), dim3(256), 0, s, vol, n, plane, minD, disp);
+    }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

@@ -123,18 +123,18 @@ __device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v)
 // A workgroup owns 256 columns x SIM_ROWS rows and runs through a chunk of up to SIM_DCH candidates itself: the left
 // pixel and gradient stay in registers, the right-image row segment every candidate shifts over (256 + chunk - 1
 // columns, colours packed BGRX, gradients as 3 x i16) is staged in LDS once, so the images are read from HBM ~1.5x
-// instead of once per candidate.  grid: (ceil(W/256), ceil(H/SIM_ROWS), ceil(numD/SIM_DCH)); plane k <-> offset minD+k.
+// instead of once per candidate.  grid: (ceil(W/256), ceil(H/SIM_ROWS), ceil(numD/dch)), dch <= SIM_DCH; plane k <-> offset minD+k.
 constexpr int SIM_ROWS = 4;
 constexpr int SIM_DCH = 512;
 __global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
                                                     const short* __restrict__ gL, const short* __restrict__ gR, int H, int W,
                                                     int minD, int numD, float rr, float rg, float thresCf, int tCi, float tGdn,
-                                                    float thresGf, float* __restrict__ cost,
+                                                    float thresGf, int dch, float* __restrict__ cost,
                                                     uint32_t* __restrict__ parts /* optional [numD][waves][2] min/max keys */)
 {
     extern __shared__ __align__(16) uint32_t sim_smem[];
     const int tid = threadIdx.x, x0 = blockIdx.x * 256, y0 = blockIdx.y * SIM_ROWS;
-    const int kb = blockIdx.z * SIM_DCH, ke = min(numD, kb + SIM_DCH);
+    const int kb = blockIdx.z * dch, ke = min(numD, kb + dch);
     const int max_off = minD + numD - 1, Wb = W + max_off;
     const int WL = 256 + (ke - kb) - 1, WLp = (WL + 1) & ~1;
     const int u0 = x0 - (minD + ke - 1);  // u = x - offset: leftmost shifted column this chunk touches
@@ -333,7 +333,13 @@ int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const s
                       int minD, int numD, double regularity, double thresC, double thresG, float* cost, uint32_t* ord_scratch,
                       float2* scales)
 {
-    const int nz = (numD + SIM_DCH - 1) / SIM_DCH, chunk = numD < SIM_DCH ? numD : SIM_DCH;
+    // candidates per workgroup: all of them (up to SIM_DCH) when the frame alone fills the chip (1080p: 2160 workgroups);
+    // small frames split the range so that ~2000 workgroups exist (640x360 D=64: 270 -> 2160), at the price of staging the
+    // right-image row segment once per split
+    int dch = SIM_DCH;
+    const long long wg_xy = (long long)((W + 255) / 256) * ((H + SIM_ROWS - 1) / SIM_ROWS);
+    while (dch > 8 && wg_xy * ((numD + dch - 1) / dch) < 2048) dch /= 2;
+    const int nz = (numD + dch - 1) / dch, chunk = numD < dch ? numD : dch;
     dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, nz);
     const int WLp = (256 + chunk - 1 + 1) & ~1;
     const size_t lds = (size_t)SIM_ROWS * WLp * 12;
@@ -345,7 +351,7 @@ int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const s
     float tGdn = (float)thresG;
     if ((double)tGdn > thresG) tGdn = nextafterf(tGdn, -INFINITY);
     hipLaunchKernelGGL(k_similarity, grid, dim3(256), lds, s, L, R, gL, gR, H, W, minD, numD, rr, rg, thresCf, tCi, tGdn,
-                       (float)thresG, cost, ord_scratch);
+                       (float)thresG, dch, cost, ord_scratch);
     if (ord_scratch && scales)
         hipLaunchKernelGGL(k_scales_from_parts, dim3(numD), dim3(256), 0, s, ord_scratch, (int)(grid.x * grid.y * 4), scales);
     ASW_HIP_TRY(hipGetLastError());

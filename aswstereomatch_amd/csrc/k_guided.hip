@@ -520,6 +520,10 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     // 128 rows 6.24, 270 rows 8.15); the single-channel launches (SAD cost, BLO1) are best at 64
     int band = NP >= 4 ? 32 : 64;
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
+    // A launch with too few wavefronts to fill the chip (guide statistics of one slice: 578 at 1080p, 72 at 640x360) is bound by
+    // the latency of its serial row walk, not by throughput: shorter bands mean shorter walks and more wavefronts, and the
+    // redundant warm-up rows cost nothing there.
+    while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
     auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
