@@ -271,18 +271,23 @@ __global__ __launch_bounds__(256) void k_minmax_u8(const uint8_t* __restrict__ i
 }
 
 // per-column min/max over rows and channels of an interleaved 3-channel u8 image -> colmm[2*W] (u8 values)
+// (init: {255, 0} per column).  A workgroup covers 64 columns x 64 rows, four row lanes per column; one thread per column
+// walking all H rows took 0.44 ms at 1080p -- pure load latency.
 __global__ __launch_bounds__(256) void k_col_minmax_u8(const uint8_t* __restrict__ img, int H, int W, int* __restrict__ colmm)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * 64 + (threadIdx.x >> 6), y1 = min(H, blockIdx.y * 64 + 64);
     if (x >= W) return;
     int lo = 255, hi = 0;
-    for (int y = 0; y < H; y++) {
+    for (int y = y0; y < y1; y += 4) {
         const uint8_t* p = img + ((size_t)y * W + x) * 3;
         lo = min(lo, min((int)p[0], min((int)p[1], (int)p[2])));
         hi = max(hi, max((int)p[0], max((int)p[1], (int)p[2])));
     }
-    colmm[2 * x] = lo;
-    colmm[2 * x + 1] = hi;
+    if (lo <= hi) {
+        atomicMin(&colmm[2 * x], lo);
+        atomicMax(&colmm[2 * x + 1], hi);
+    }
 }
 
 // ord[2*n] -> scales[n] (float2 {a, b})
@@ -297,20 +302,27 @@ __global__ void k_scales_from_ord(const uint32_t* __restrict__ ord, int n, float
 // [L, R shifted by d through the REFLECT pad]; its min/max run over L and over the right-image columns
 // the shifted view actually contains: reflect(x-d), x in [0,W)  ==  columns [0, max(d-1, W-1-d)] when
 // d < W (larger d: walk the reflection explicitly).
-__global__ void k_guide_scales_lr(const uint32_t* __restrict__ ordL, const int* __restrict__ colmmR, int W, int minD, int numD,
-                                  int disp_type, float2* __restrict__ scales)
+// One wavefront per slice, lanes striding over the columns.
+__global__ __launch_bounds__(64) void k_guide_scales_lr(const uint32_t* __restrict__ ordL, const int* __restrict__ colmmR, int W,
+                                                        int minD, int numD, int disp_type, float2* __restrict__ scales)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= numD) return;
+    const int k = blockIdx.x;
     const int d = minD + k;
     int lo = 255, hi = 0;
-    for (int x = 0; x < W; x++) {
+    for (int x = threadIdx.x; x < W; x += 64) {
         int c = disp_type == ASW_DISPARITY_LEFT ? reflect_idx(x - d, W) : reflect_idx(x + d, W);
         lo = min(lo, colmmR[2 * c]);
         hi = max(hi, colmmR[2 * c + 1]);
     }
-    double mn = fmin((double)ord2f(ordL[0]), (double)lo), mx = fmax((double)ord2f(ordL[1]), (double)hi);
-    scales[k] = minmax_scale(mn, mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if (threadIdx.x == 0) {
+        double mn = fmin((double)ord2f(ordL[0]), (double)lo), mx = fmax((double)ord2f(ordL[1]), (double)hi);
+        scales[k] = minmax_scale(mn, mx);
+    }
 }
 
 __global__ void k_fill_u32(uint32_t* p, int n, uint32_t a, uint32_t b)
@@ -400,9 +412,9 @@ int launch_guide_scales_lr(hipStream_t s, const uint8_t* ref_img, const uint8_t*
 {
     int rc = launch_u8_scale(s, ref_img, (size_t)H * W * 3, ord_scratch, nullptr);
     if (rc != ASW_OK) return rc;
-    hipLaunchKernelGGL(k_col_minmax_u8, dim3((W + 255) / 256), dim3(256), 0, s, shifted_img, H, W, colmm_scratch);
-    hipLaunchKernelGGL(k_guide_scales_lr, dim3((numD + 255) / 256), dim3(256), 0, s, ord_scratch, colmm_scratch, W, minD, numD,
-                       disp_type, scales);
+    hipLaunchKernelGGL(k_fill_u32, dim3((2 * W + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint32_t*>(colmm_scratch), 2 * W, 255u, 0u);
+    hipLaunchKernelGGL(k_col_minmax_u8, dim3((W + 63) / 64, (H + 63) / 64), dim3(256), 0, s, shifted_img, H, W, colmm_scratch);
+    hipLaunchKernelGGL(k_guide_scales_lr, dim3(numD), dim3(64), 0, s, ord_scratch, colmm_scratch, W, minD, numD, disp_type, scales);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

@@ -509,7 +509,7 @@ struct PlaneDst {
     __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[1]) const { c.o[(size_t)y * W] = m[0]; }
 };
 template <int NP, int CPL, int ND, class Src, class Dst>
-int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
+int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
 {
     constexpr int SW = 64 * CPL;
     if (k < 1 || k > SW / 2) return ASW_ERR_BAD_ARGUMENT;  // k-1 halo columns must leave outputs in the strip
@@ -523,7 +523,9 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     // A launch with too few wavefronts to fill the chip (guide statistics of one slice: 578 at 1080p, 72 at 640x360) is bound by
     // the latency of its serial row walk, not by throughput: shorter bands mean shorter walks and more wavefronts, and the
     // redundant warm-up rows cost nothing there.
-    while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n + ND - 1) / ND) < 4096) band /= 2;
+    // (n_active: slices that do not leave at once -- consumers that skip slices or strips say how many they expect)
+    const int n_eff = n_active > 0 && n_active < n ? n_active : n;
+    while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n_eff + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
     auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
@@ -540,7 +542,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
 }
 
 template <int NP, int ND = 1, class Src, class Dst>
-int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n)
+int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
 {
     // Measured on MI355X (1080p D=128): <CPL,prefetch> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
     // pair of launches; 24.3 / 24.9 / 24.3 / 24.1 ms for NP=7.  The kernels are bound by the memory system
@@ -548,7 +550,7 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     // columns per lane save the shared horizontal sum, ND slices per wavefront share the slice-independent loads.
     // ND > 1 (several slices per wavefront sharing guide pixel and statistics) was measured and rejected: <CPL,ND> =
     // <2,1> 6.2 ms, <2,2> 7.4, <1,2> 7.5, <1,4> 9.7 -- the extra registers cost more occupancy than the traffic saves.
-    return launch_walk_t<NP, 2, ND>(s, src, dst, H, W, k, n);
+    return launch_walk_t<NP, 2, ND>(s, src, dst, H, W, k, n, n_active);
 }
 
 
@@ -633,15 +635,18 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         StatsSrc<6, 1, true> u1{gu};
         // fixed word: representatives only
         StatsDst<1> df{sp.half[1 - sp.shifted], sp, a.H, a.W, epsf};
-        rc = sp.shifted == 1 ? launch_walk<6>(s, s0, df, a.H, a.W, a.r, a.n) : launch_walk<6>(s, s1, df, a.H, a.W, a.r, a.n);
+        const int n_rep = 4;  // scale groups are few (natural images: the global extrema are visible at nearly every d)
+        rc = sp.shifted == 1 ? launch_walk<6>(s, s0, df, a.H, a.W, a.r, a.n, n_rep) : launch_walk<6>(s, s1, df, a.H, a.W, a.r, a.n, n_rep);
         if (rc != ASW_OK) return rc;
         // shifted word's image without the shift: representatives only
         StatsDst<1> du{sp.unshifted, sp, a.H, a.W, epsf};
-        rc = sp.shifted == 1 ? launch_walk<6>(s, u1, du, a.H, a.W, a.r, a.n) : launch_walk<6>(s, u0, du, a.H, a.W, a.r, a.n);
+        rc = sp.shifted == 1 ? launch_walk<6>(s, u1, du, a.H, a.W, a.r, a.n, n_rep) : launch_walk<6>(s, u0, du, a.H, a.W, a.r, a.n, n_rep);
         if (rc != ASW_OK) return rc;
         // shifted word as the guide shows it: border strips of every slice
         StatsDst<2> db{sp.half[sp.shifted], sp, a.H, a.W, epsf};
-        rc = sp.shifted == 1 ? launch_walk<6>(s, s1, db, a.H, a.W, a.r, a.n) : launch_walk<6>(s, s0, db, a.H, a.W, a.r, a.n);
+        const int nstrips = (a.W + (128 - a.r)) / (129 - a.r);  // strips of a two-column-per-lane walk
+        const int n_border = (int)(((long long)a.n * 3 + nstrips - 1) / nstrips);  // ~3 strips of a slice touch its border columns
+        rc = sp.shifted == 1 ? launch_walk<6>(s, s1, db, a.H, a.W, a.r, a.n, n_border) : launch_walk<6>(s, s0, db, a.H, a.W, a.r, a.n, n_border);
         if (rc != ASW_OK) return rc;
     }
     ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
