@@ -178,8 +178,9 @@ __global__ __launch_bounds__(256) void k_lr_check(const float* __restrict__ dl, 
     bool bad = false;
     if (x < W && y < H) {
         const float d = dl[(size_t)y * W + x];
-        const int xr = x - (int)d;
-        bad = !(xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + min(max(xr, 0), W - 1)]) <= max_diff);  // NaN fails too
+        const bool sane = fabsf(d) < 16777216.0f;  // NaN, inf and values no disparity can take: rejected before the int cast
+        const int xr = x - (sane ? (int)d : 0);
+        bad = !(sane && xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + min(max(xr, 0), W - 1)]) <= max_diff);
         out[(size_t)y * W + x] = bad ? invalid : d;
     }
     const unsigned long long m = __ballot(bad);

@@ -1327,8 +1327,9 @@ int orc_lr_check(const float* dl, const float* dr, int H, int W, float max_diff,
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const float d = dl[(size_t)y * W + x];
-            const int xr = x - (int)d;
-            const int ok = xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + (xr < 0 ? 0 : xr >= W ? W - 1 : xr)]) <= max_diff;
+            const int sane = fabsf(d) < 16777216.0f; /* NaN, inf, absurd values: rejected before the int cast */
+            const int xr = x - (sane ? (int)d : 0);
+            const int ok = sane && xr >= 0 && xr < W && fabsf(d - dr[(size_t)y * W + (xr < 0 ? 0 : xr >= W ? W - 1 : xr)]) <= max_diff;
             out[(size_t)y * W + x] = ok ? d : invalid;
             bad += !ok;
         }

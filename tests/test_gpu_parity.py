@@ -499,9 +499,10 @@ def test_left_right_check(ctx, oracle):
     assert 0.5 < kept.mean() < 1.0                      # occlusions and border columns are rejected, the bulk survives
     assert (np.abs(got[kept] - gt[kept]) <= 1).mean() > 0.9   # and what survives is mostly right
     # NaN / out-of-image targets
-    a = np.array([[np.nan, 5.0, 1.0, 0.0]], np.float32)
-    b = np.array([[0.0, 9.0, 9.0, 0.0]], np.float32)
+    a = np.array([[np.nan, 5.0, 1.0, 0.0, np.inf, -1e30]], np.float32)
+    b = np.array([[0.0, 9.0, 9.0, 0.0, np.inf, 0.0]], np.float32)
     got, bad = ctx.leftRightCheck(a, b, 1.0, -2.0)
-    assert np.array_equal(got, [[-2.0, -2.0, -2.0, 0.0]]) and bad == 3
+    assert np.array_equal(got, [[-2.0, -2.0, -2.0, 0.0, -2.0, -2.0]]) and bad == 5
+    assert np.array_equal(got, oracle.lr_check(a, b, 1.0, -2.0)[0])
     with pytest.raises(asw.AswError):
         ctx.leftRightCheck(a, b, -1.0)

@@ -657,13 +657,14 @@ def test_lr_check_rule(oracle):
     dl = rng.integers(0, 9, (7, 20)).astype(np.float32)
     dr = rng.integers(0, 9, (7, 20)).astype(np.float32)
     dl[0, 0] = np.nan
+    dl[1, 1], dl[2, 2], dl[3, 3] = np.inf, -3e9, 1e30
     for tau in (0.0, 1.0, 2.5):
         out, bad = oracle.lr_check(dl, dr, tau, -7.0)
         want = np.full(dl.shape, -7.0, np.float32)
         for y in range(7):
             for x in range(20):
                 d = dl[y, x]
-                if not np.isnan(d):
+                if np.isfinite(d) and abs(d) < 2 ** 24:
                     xr = x - int(d)
                     if 0 <= xr < 20 and abs(d - dr[y, xr]) <= tau:
                         want[y, x] = d
