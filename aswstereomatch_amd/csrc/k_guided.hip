@@ -508,7 +508,7 @@ struct PlaneDst {
     __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
     __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[1]) const { c.o[(size_t)y * W] = m[0]; }
 };
-template <int NP, int CPL, int ND, class Src, class Dst>
+template <int NP, int CPL, int ND, int WPE = 4, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
 {
     constexpr int SW = 64 * CPL;
@@ -528,7 +528,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n_eff + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
-    auto kern = k_box_walk<NP, CPL, ND, 4, Src, Dst>;
+    auto kern = k_box_walk<NP, CPL, ND, WPE, Src, Dst>;
     // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
     // GuidedF_2 -1 %); four strips of the one slice otherwise
     const int slice_par = (n + ND - 1) / ND >= 4 ? 1 : 0;
@@ -651,7 +651,8 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     }
     ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
     ABDst<6> dst{sp, a.ab, a.H, a.W};
-    // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms)
+    // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
+    // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
     rc = launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
     QSrc<6> qs{a.ab, a.H, a.W};
