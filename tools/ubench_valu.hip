@@ -61,6 +61,24 @@ KERNEL(k_cvt_f32_ubyte, float a0 = 0; float a1 = 0; float a2 = 0; float a3 = 0; 
                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));,
        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3)
 
+KERNEL(k_and_shift, unsigned a0 = threadIdx.x; unsigned a1 = a0 + 1; unsigned a2 = a0 + 2; unsigned a3 = a0 + 3; unsigned b = 0x12345678u;,
+       asm volatile("v_and_b32 %0, 0xff, %4\n v_lshrrev_b32 %1, 24, %4\n v_and_b32 %2, 0xff, %4\n v_lshrrev_b32 %3, 24, %4\n"
+                    "v_and_b32 %0, 0xff, %4\n v_lshrrev_b32 %1, 24, %4\n v_and_b32 %2, 0xff, %4\n v_lshrrev_b32 %3, 24, %4\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3))
+
+KERNEL(k_minmax_u32, unsigned a0 = threadIdx.x; unsigned a1 = a0 + 1; unsigned a2 = a0 + 2; unsigned a3 = a0 + 3; unsigned b = 0x12345678u;,
+       asm volatile("v_min_u32 %0, %0, %4\n v_max_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_max_u32 %3, %3, %4\n"
+                    "v_min_u32 %0, %0, %4\n v_max_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_max_u32 %3, %3, %4\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3))
+
+KERNEL(k_cvt_ubyte8, float a0 = 0; float a1 = 0; float a2 = 0; float a3 = 0; unsigned b = threadIdx.x * 0x01010101u;,
+       asm volatile("v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4\n"
+                    "v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3)
+
 KERNEL(k_mul_f32, float a0 = threadIdx.x; float a1 = a0 + 1; float a2 = a0 + 2; float a3 = a0 + 3; float b = 1.0001f;,
        asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n"
                     "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n"
@@ -87,7 +105,7 @@ int main()
     hipMalloc(&out, 1 << 24);
     struct { const char* name; kern_t k; } ks[] = {
         {"v_fma_f32", k_fma_f32}, {"v_mul_f32", k_mul_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_bfe_u32", k_bfe_u32},
-        {"v_cvt_f32_ubyteN", k_cvt_f32_ubyte}, {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64},
+        {"v_cvt_f32_ubyteN (x1.5)", k_cvt_f32_ubyte}, {"v_cvt_f32_ubyteN", k_cvt_ubyte8}, {"v_and/lshrrev_b32", k_and_shift}, {"v_min/max_u32", k_minmax_u32}, {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64},
         {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f64_u32", k_cvt_f64_u32}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
