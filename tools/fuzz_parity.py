@@ -50,7 +50,7 @@ def main():
         seed = int(rng.integers(0, 1 << 30))
         L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
-                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid"]))
+                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
         try:
             if method == "classic":
@@ -89,6 +89,14 @@ def main():
                 rc, dw, vw = O.asw_bilgrid(L, R, 0, sS, sR, minD, nD, want_vol=True)
                 d, v = ctx.computeAdaptiveWeight_bilateralGrid(L, R, 0, sS, sR, minD, nD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+            elif method == "lrcheck":
+                a = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
+                b = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
+                a[rng.random((H, W)) < 0.02] = np.nan
+                tau = float(rng.choice([0.0, 1.0, 2.5]))
+                want, wbad = O.lr_check(a, b, tau, -1.0)
+                got, bad = ctx.leftRightCheck(a, b, tau, -1.0)
+                ok = np.array_equal(got, want) and bad == wbad
             elif method == "wmedian":
                 win = min(win, 17)
                 rc, dw, vw = O.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)
