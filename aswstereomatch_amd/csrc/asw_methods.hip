@@ -77,7 +77,7 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int kind, int win, double gamma
         taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256;
     }
     for (int i = nt; i < nt_pad; i++) taps[i] = make_int4(0, 0, 0, zero_cls * 256);
-    ASW_TRY(t.taps.ensure(taps.size() * sizeof(int4)));
+    ASW_TRY(t.taps.ensure((taps.size() > 4 ? taps.size() : 4) * sizeof(int4)));  // never a null table, even for win = 1 (no taps)
     ASW_TRY(t.lut.ensure(lut.size() * sizeof(float)));
     if (!taps.empty())  // win = 1 has no taps at all (every E is 0/0)
         ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));

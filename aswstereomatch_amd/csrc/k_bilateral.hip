@@ -214,7 +214,7 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
         if (doB) wb = lut_at(lut, ib);
     };
     __syncthreads();  // cost tile complete
-    gather(0);
+    if (p.ntaps > 0) gather(0);  // win = 1 has no taps: nothing to stage, and the tap table may be empty
     for (int g0 = 0; g0 < p.ntaps; g0 += G) {
         // same-wavefront LDS traffic is ordered: these writes follow the previous group's reads and precede this group's
 #pragma unroll

@@ -183,3 +183,19 @@ def test_batch_on_a_missing_device_fails_cleanly():
     # and the scheduler still works afterwards
     out = asw.stereoMatchingBatch([L], [R], LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 4, device_ids=[0])
     assert out[0].shape == (16, 32)
+
+
+def test_window_one_on_a_fresh_context(oracle):
+    """win = 1 has no taps at all; on a context whose tap table was never allocated the kernel once read it anyway
+    (GPU memory fault found by tools/fuzz_parity.py --seed 99: direct8, 14 x 344, win 1 as the first bilateral call)."""
+    L, R, _ = make_pair(14, 344, 12, seed=587025979, block=8)
+    for which in ("direct8", "classic"):
+        c = asw.Context(0)
+        if which == "direct8":
+            d, v = c.computeAdaptiveWeight_direct8(L, R, LEFT, 1, 0, 12, return_cost_volume=True)
+            rc, dw, vw = oracle.asw_direct8(L, R, 0, 1, 0, 12, want_vol=True)
+        else:
+            d, v = c.computeAdaptiveWeight(L, R, 30, 20, LEFT, 1, 0, 12, return_cost_volume=True)
+            rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 1, 0, 12, want_vol=True)
+        c.close()
+        assert rc == 0 and np.array_equal(d, dw) and np.array_equal(v, vw, equal_nan=True)

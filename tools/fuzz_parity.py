@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-h", type=int, default=70)
     ap.add_argument("--max-w", type=int, default=260)
+    ap.add_argument("--fresh-every", type=int, default=300, help="recreate the context every N cases: first-use paths (unallocated tables, scratch growth) get exercised in many orders")
+    ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = asw.Context(0)
@@ -52,6 +54,11 @@ def main():
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
                                 "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
+        if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
+            ctx.close()
+            ctx = asw.Context(0)
+        if args.trace:
+            print("case", n, tag, flush=True)
         try:
             if method == "classic":
                 rc, dw, vw = O.asw_classic(L, R, 30, 20, dt, win, minD, numD, want_vol=True)
