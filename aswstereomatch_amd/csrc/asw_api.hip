@@ -328,6 +328,7 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     ASW_TRY(launch_slice_scales(ctx->stream, raw.as<float>(), 1, plane, ord.as<uint32_t>(), psc.as<float2>()));     // M.cpp:2775
     GuidedLaunch a;
     a.shiftA = 0; a.shiftB = 0; a.C = C; a.guide_per_slice = 0;
+    a.nan_safe = 1;  // p is the caller's: it may hold NaN
     a.guideA = pxa.as<uint32_t>(); a.guideB = C == 6 ? pxb.as<uint32_t>() : nullptr;
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;

@@ -146,6 +146,7 @@ struct GuidedLaunch {
     const float2* pscales;  // per-slice normalize() parameters of P
     int H, W, n, r, minD;
     double eps;
+    int nan_safe;           // 1: P may hold NaN (NCC costs of flat windows; caller-supplied P): window sums are rebuilt when a running sum is poisoned
     float* stats;           // scratch, guided_stats_floats(): {meanI_c, var_c+eps} interleaved per pixel and BGRX word
     int* rep_scratch;       // scratch, n ints (or null): scale-group representative of every slice (6-channel per-slice guides)
     float* ab;              // scratch, guided_ab_floats(): {a_c, b} interleaved per pixel

@@ -281,6 +281,7 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     GuidedLaunch a;
     // guide = [L, R shifted by -d] (LEFT, M.cpp:2907-2912) or [L shifted by +d, R] (RIGHT, M.cpp:2925-2929)
     a.shiftA = (!plain3 && right) ? 1 : 0; a.shiftB = (!plain3 && !right) ? -1 : 0; a.C = C; a.guide_per_slice = plain3 ? 0 : 1;
+    a.nan_safe = ncc ? 1 : 0;  // SAD and TAD C+G costs are finite; an NCC cost is 0/0 where a window is flat
     const uint8_t* dGuide3 = variant2 ? dL : dR;  // the 3-channel guide: left image (GuidedF_2) / right image (GuidedF_3 RIGHT)
     ASW_TRY(launch_pack_words(ctx->stream, plain3 ? dGuide3 : dL, H, W, 3, 0, pxa.as<uint32_t>()));
     if (!plain3) ASW_TRY(launch_pack_words(ctx->stream, dR, H, W, 3, 0, pxb.as<uint32_t>()));

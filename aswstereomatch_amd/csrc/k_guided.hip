@@ -30,7 +30,11 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 //     no workgroup barrier is needed; a lane's second column reuses the first one's sum (- b[0] + b[k]).
 //   * ND slices per wavefront: operands that do not depend on the slice (guide pixel, guide statistics) are
 //     fetched once -- the ND fetches are issued back to back with identical addresses and merge (CSE).
-template <int NP, int CPL, int ND, int WPE, class Src, class Dst>
+//   * NANSAFE: the inputs may hold NaN (0/0 NCC costs of flat windows, M.cpp:867-868).  A sliding sum never loses a NaN once it
+//     has entered (NaN - NaN = NaN), whereas a window sum is NaN only while the NaN is inside the window -- the form the CPU
+//     restatement defines.  Whenever a running sum is not finite it is therefore rebuilt from the k rows of its window (and
+//     the shared horizontal sum of the second column from its own k terms); finite data never takes these branches.
+template <int NP, int CPL, int ND, int WPE, bool NANSAFE, class Src, class Dst>
 __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
 {
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
@@ -128,6 +132,25 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                 src.eval(rn[c][n], scol[c][n], v);
 #pragma unroll
                 for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] + (double)v[p];
+                if constexpr (NANSAFE) {
+                    bool poisoned = false;
+#pragma unroll
+                    for (int p = 0; p < NP; p++) poisoned = poisoned || !__builtin_isfinite(vs[c][n][p]);
+                    if (poisoned && s >= k - 1) {  // rebuild the window sum of rows s-k+1 .. s (ascending)
+                        double acc[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; p++) acc[p] = 0.0;
+                        for (int i = k - 1; i >= 0; i--) {
+                            const typename Src::Raw rr = src.fetch(reflect101_idx(y0 - hl + s - i, H), scol[c][n]);
+                            float w[NP];
+                            src.eval(rr, scol[c][n], w);
+#pragma unroll
+                            for (int p = 0; p < NP; p++) acc[p] = acc[p] + (double)w[p];
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; p++) vs[c][n][p] = acc[p];
+                    }
+                }
             }
         if (s >= k - 1) {
 #pragma unroll
@@ -150,6 +173,12 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                         m[0][p] = (float)(sum * scale);
                         if constexpr (CPL > 1) {
                             double sum1 = (sum - b[0]) + b[k];  // window of the adjacent column
+                            if constexpr (NANSAFE) {
+                                if (!__builtin_isfinite(sum1)) {
+                                    sum1 = 0.0;
+                                    for (int i = 1; i <= k; i++) sum1 = sum1 + b[i];
+                                }
+                            }
                             m[CPL - 1][p] = (float)(sum1 * scale);
                         }
                     }
@@ -508,7 +537,7 @@ struct PlaneDst {
     __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
     __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[1]) const { c.o[(size_t)y * W] = m[0]; }
 };
-template <int NP, int CPL, int ND, int WPE = 4, class Src, class Dst>
+template <int NP, int CPL, int ND, int WPE = 4, bool NANSAFE = false, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
 {
     constexpr int SW = 64 * CPL;
@@ -528,7 +557,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n_eff + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
-    auto kern = k_box_walk<NP, CPL, ND, WPE, Src, Dst>;
+    auto kern = k_box_walk<NP, CPL, ND, WPE, NANSAFE, Src, Dst>;
     // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
     // GuidedF_2 -1 %); four strips of the one slice otherwise
     const int slice_par = (n + ND - 1) / ND >= 4 ? 1 : 0;
@@ -541,7 +570,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     return ASW_OK;
 }
 
-template <int NP, int ND = 1, class Src, class Dst>
+template <int NP, int ND = 1, bool NANSAFE = false, class Src, class Dst>
 int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
 {
     // Measured on MI355X (1080p D=128): <CPL,prefetch> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
@@ -550,7 +579,7 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     // columns per lane save the shared horizontal sum, ND slices per wavefront share the slice-independent loads.
     // ND > 1 (several slices per wavefront sharing guide pixel and statistics) was measured and rejected: <CPL,ND> =
     // <2,1> 6.2 ms, <2,2> 7.4, <1,2> 7.5, <1,4> 9.7 -- the extra registers cost more occupancy than the traffic saves.
-    return launch_walk_t<NP, 2, ND>(s, src, dst, H, W, k, n, n_active);
+    return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active);
 }
 
 
@@ -592,11 +621,11 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         if (rc != ASW_OK) return rc;
         ABSrc<3, false> src{g, a.P, a.pscales, a.H, a.W};
         ABDst<3> dst{sp, a.ab, a.H, a.W};
-        rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
+        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
         QDst<3, false> qd{g, a.q, a.H, a.W};
-        return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
+        return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
     }
     GuideAccT<true> g{a.guideA, a.guideB, a.gscales, a.guide_per_slice ? 1 : 0, a.W, a.shiftA, a.shiftB, a.minD};
     if (a.C == 3) {
@@ -606,11 +635,11 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         if (rc != ASW_OK) return rc;
         ABSrc<3, true> src{g, a.P, a.pscales, a.H, a.W};
         ABDst<3> dst{sp, a.ab, a.H, a.W};
-        rc = launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
+        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
         if (rc != ASW_OK) return rc;
         QSrc<3> qs{a.ab, a.H, a.W};
         QDst<3, true> qd{g, a.q, a.H, a.W};
-        return launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
+        return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
     }
     // 6-channel guide
     const bool share = a.guide_per_slice && a.rep_scratch && ((a.shiftA != 0) != (a.shiftB != 0));
@@ -653,11 +682,11 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     ABDst<6> dst{sp, a.ab, a.H, a.W};
     // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
-    rc = launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
+    rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
     QSrc<6> qs{a.ab, a.H, a.W};
     QDst<6, true> qd{g, a.q, a.H, a.W};
-    return launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);  // two columns per lane: 4.5 ms, one: 5.3 ms
+    return a.nan_safe ? launch_walk<7, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);  // two columns per lane: 4.5 ms, one: 5.3 ms
 }
 
 // interleaved C-channel 8U image -> BGRX word planes (channels 3w..3w+2 in plane w)

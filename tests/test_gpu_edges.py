@@ -199,3 +199,32 @@ def test_window_one_on_a_fresh_context(oracle):
             rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 1, 0, 12, want_vol=True)
         c.close()
         assert rc == 0 and np.array_equal(d, dw) and np.array_equal(v, vw, equal_nan=True)
+
+
+def test_nan_costs_stay_inside_their_windows(ctx, oracle):
+    """Flat windows give 0/0 NCC costs (M.cpp:867-868).  A NaN must poison exactly the box windows that contain it (the CPU
+    restatement's definition) -- not everything below it in the band or the next column of a lane pair, which is what plain
+    sliding sums do.  Found by tools/fuzz_parity.py --fresh-every 1 --seed 123 (guided3, 1 x 247)."""
+    L, R, _ = make_pair(40, 200, 12, seed=5, block=8)
+    L[10:16, 50:60] = 77        # flat patches: every 3x3 / 5x5 window inside is constant -> NCC = 0/0
+    R[10:16, 40:52] = 91
+    L[30:33, 120:126] = 5
+    for win, dt in ((3, LEFT), (5, LEFT), (3, RIGHT)):
+        rc, dw, vw = oracle.asw_guided3(L, R, dt, 1e-6, win, 0, 12, want_vol=True)
+        d, v = ctx.computeAdaptiveWeight_GuidedF_3(L, R, dt, 1e-6, win, 0, 12, return_cost_volume=True)
+        assert rc == 0 and np.isnan(vw).any() and np.isfinite(vw).mean() > 0.5
+        assert np.array_equal(np.isnan(v), np.isnan(vw)), (win, dt)
+        fin = np.isfinite(vw)
+        assert np.allclose(v[fin], vw[fin], rtol=1e-4, atol=1e-30)
+        ok = fin.all(axis=0)
+        assert np.array_equal(d[ok], dw[ok])
+    # the public guided filter with NaN in the caller's P
+    rng = np.random.default_rng(8)
+    P = rng.random((40, 200), dtype=np.float32)
+    P[7, 9] = np.nan
+    P[20:22, 100:103] = np.nan
+    for guide in (L, np.concatenate([L, R], axis=2)):
+        rc, qw = oracle.guided_filter(guide, P, 7, 1e-6)
+        q = ctx.getGuidedFilter(guide, P, 7, 1e-6)
+        assert rc == 0 and np.array_equal(np.isnan(q), np.isnan(qw)) and 0 < np.isnan(qw).mean() < 0.2
+        assert np.allclose(q[np.isfinite(qw)], qw[np.isfinite(qw)], rtol=1e-4, atol=1e-30)
