@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--max-h", type=int, default=70)
     ap.add_argument("--max-w", type=int, default=260)
     ap.add_argument("--fresh-every", type=int, default=300, help="recreate the context every N cases: first-use paths (unallocated tables, scratch growth) get exercised in many orders")
+    ap.add_argument("--flat", type=float, default=0.25, help="share of the cases whose images get constant rectangles (flat windows: 0/0 NCC costs, zero variances, ties)")
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -51,6 +52,11 @@ def main():
         dt = int(rng.integers(0, 2))
         seed = int(rng.integers(0, 1 << 30))
         L, R, _ = make_pair(H, W, max(2, numD // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
+        if rng.random() < args.flat:
+            for img in (L, R):
+                for _ in range(int(rng.integers(1, 4))):
+                    y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                    img[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 40))] = rng.integers(0, 256, 3).astype(np.uint8)
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
                                 "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
