@@ -67,8 +67,9 @@ def main():
             print("case", n, tag, flush=True)
         try:
             if method == "classic":
-                rc, dw, vw = O.asw_classic(L, R, 30, 20, dt, win, minD, numD, want_vol=True)
-                d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, win, minD, numD, return_cost_volume=True)
+                gc, gg = float(rng.choice([30, 5, 0.5, 100])), float(rng.choice([20, 2, 7.5, 60]))
+                rc, dw, vw = O.asw_classic(L, R, gc, gg, dt, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight(L, R, gc, gg, dt, win, minD, numD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
             elif method == "direct8":
                 rc, dw, vw = O.asw_direct8(L, R, 0, win, minD, numD, want_vol=True)
@@ -80,12 +81,14 @@ def main():
                 d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, win, minD, numD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
             elif method == "guided":
-                rc, dw, vw = O.asw_guided(L, R, dt, 1e-6, win, minD, numD, want_vol=True)
-                d, v = ctx.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, win, minD, numD, return_cost_volume=True)
+                eps = float(rng.choice([1e-6, 1e-8, 1e-3]))
+                rc, dw, vw = O.asw_guided(L, R, dt, eps, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_GuidedF(L, R, dt, eps, win, minD, numD, return_cost_volume=True)
                 ok = close(v, vw) and np.array_equal(d, dw)
             elif method == "guided2":
-                rc, dw, vw = O.asw_guided2(L, R, 0, 1e-6, win, minD, numD, want_vol=True)
-                d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, 0, 1e-6, win, minD, numD, return_cost_volume=True)
+                eps = float(rng.choice([1e-6, 1e-8, 1e-3]))
+                rc, dw, vw = O.asw_guided2(L, R, 0, eps, win, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_GuidedF_2(L, R, 0, eps, win, minD, numD, return_cost_volume=True)
                 ok = close(v, vw) and np.array_equal(d, dw)
             elif method == "guided3":
                 rc, dw, vw = O.asw_guided3(L, R, dt, 1e-6, win, minD, numD, want_vol=True)
@@ -112,12 +115,14 @@ def main():
                 ok = np.array_equal(got, want) and bad == wbad
             elif method == "wmedian":
                 win = min(win, 17)
-                rc, dw, vw = O.asw_wmedian(L, R, 0, win, 10, 10, minD, numD, want_vol=True)
-                d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, 0, win, 10, 10, minD, numD, return_cost_volume=True)
+                rs, rr = [(10, 10), (5, 20), (3, 3), (25, 2.5)][int(rng.integers(0, 4))]
+                rc, dw, vw = O.asw_wmedian(L, R, 0, win, rs, rr, minD, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, 0, win, rs, rr, minD, numD, return_cost_volume=True)
                 ok = np.array_equal(v, vw) and np.array_equal(d, dw)
             elif method == "blo1":
-                rc, dw, vw = O.asw_blo1(L, R, dt, 0.015, win, 0, numD, want_vol=True)
-                d, v = ctx.computeAdaptiveWeight_BLO1(L, R, dt, 0.015, win, 0, numD, return_cost_volume=True)
+                rate = float(rng.choice([0.015, 0.05, 0.004, 0.2]))
+                rc, dw, vw = O.asw_blo1(L, R, dt, rate, win, 0, numD, want_vol=True)
+                d, v = ctx.computeAdaptiveWeight_BLO1(L, R, dt, rate, win, 0, numD, return_cost_volume=True)
                 fin = np.isfinite(vw)
                 ok = np.array_equal(v[fin], vw[fin]) and np.array_equal(np.isnan(v), np.isnan(vw)) and np.array_equal(d, dw)
             elif method == "ncc":
@@ -125,13 +130,17 @@ def main():
                 ok = np.array_equal(ctx.computeNCC(L, R, dt, win, minD, numD), dw)
             elif method == "ad_tad":
                 rc, vw = O.compute_ad(L, R, dt, minD, numD)
-                rc, tw = O.compute_tad(L, R, dt, 30, minD, numD)
+                T = int(rng.integers(-5, 261))
+                rc, tw = O.compute_tad(L, R, dt, T, minD, numD)
                 ok = (np.array_equal(np.stack(ctx.computeAD(L, R, dt, minD, numD)), vw) and
-                      np.array_equal(np.stack(ctx.computeTAD(L, R, dt, 30, minD, numD)), tw) and
+                      np.array_equal(np.stack(ctx.computeTAD(L, R, dt, T, minD, numD)), tw) and
                       np.array_equal(np.stack(ctx.computeSD(L // 8, R // 8, dt, minD, numD)), O.compute_sd(L // 8, R // 8, dt, minD, numD)[1]))
             elif method == "similarity":
-                rc, vw = O.compute_similarity(L, R, 0.4, 10, 50, 0, minD, numD)
-                ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, 0.4, 10, 50, 0, minD, numD)), vw)
+                reg = float(rng.choice([0.4, 0.0, 1.0, 0.25]))
+                thc = float(rng.choice([10, 0, 254.5, 300, -1, 3.7]))
+                thg = float(rng.choice([50, 0, 0.5, 1e4, 12.3]))
+                rc, vw = O.compute_similarity(L, R, reg, thc, thg, 0, minD, numD)
+                ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, reg, thc, thg, 0, minD, numD)), vw)
             elif method == "sad":
                 rc, vw = O.cost_sad(L, R, dt, win, minD, numD)
                 ok = np.array_equal(np.stack(ctx.getCostSAD(L, R, dt, win, minD, numD)), vw)
