@@ -682,7 +682,11 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     ABDst<6> dst{sp, a.ab, a.H, a.W};
     // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
-    rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
+    // (boxes wider than 32 do not leave outputs in a 64-column strip: those take the two-column form at 148 VGPRs)
+    if (a.r > 32)
+        rc = a.nan_safe ? launch_walk_t<7, 2, 1, 3, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 3>(s, src, dst, a.H, a.W, a.r, a.n);
+    else
+        rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
     QSrc<6> qs{a.ab, a.H, a.W};
     QDst<6, true> qd{g, a.q, a.H, a.W};

@@ -228,3 +228,20 @@ def test_nan_costs_stay_inside_their_windows(ctx, oracle):
         q = ctx.getGuidedFilter(guide, P, 7, 1e-6)
         assert rc == 0 and np.array_equal(np.isnan(q), np.isnan(qw)) and 0 < np.isnan(qw).mean() < 0.2
         assert np.allclose(q[np.isfinite(qw)], qw[np.isfinite(qw)], rtol=1e-4, atol=1e-30)
+
+
+@pytest.mark.parametrize("win", [33, 35])
+def test_six_channel_guided_filter_with_the_reference_default_window(ctx, oracle, win):
+    """M.h:166-176 declares winSize = 35 as the default of the GuidedF family; the 7-plane pass of the 6-channel guide once
+    rejected boxes wider than 32 (found by the fuzz sweep with large windows)."""
+    L, R, _ = make_pair(40, 120, 10, seed=win)
+    rc, dw, vw = oracle.asw_guided(L, R, 0, 1e-6, win, 0, 10, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_GuidedF(L, R, LEFT, 1e-6, win, 0, 10, return_cost_volume=True)
+    assert rc == 0 and np.allclose(v, vw, rtol=1e-4, atol=1e-30) and np.array_equal(d, dw)
+    rc, dw, vw = oracle.asw_guided3(L, R, 0, 1e-6, win, 0, 10, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_GuidedF_3(L, R, LEFT, 1e-6, win, 0, 10, return_cost_volume=True)
+    fin = np.isfinite(vw)
+    assert rc == 0 and np.array_equal(np.isnan(v), np.isnan(vw)) and np.allclose(v[fin], vw[fin], rtol=1e-4, atol=1e-30)
+    P = np.random.default_rng(win).random((40, 120), dtype=np.float32)
+    guide = np.concatenate([L, R], axis=2)
+    assert np.allclose(ctx.getGuidedFilter(guide, P, win, 1e-6), oracle.guided_filter(guide, P, win, 1e-6)[1], rtol=1e-4, atol=1e-30)
