@@ -47,8 +47,11 @@ def main():
         H = int(rng.integers(1, args.max_h))
         W = int(rng.integers(1, args.max_w))
         win = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 21, 25, 33, 35]))
-        minD = int(rng.choice([0, 0, 0, 1, 3]))
+        minD = int(rng.choice([0, 0, 0, 1, 3, 17]))
         numD = int(rng.integers(1, 48))
+        if rng.random() < 0.08:  # long candidate ranges cross the 16-wide chunk and z-split boundaries
+            numD = int(rng.integers(48, 150))
+            H, W = min(H, 24), min(W, 96)
         dt = int(rng.integers(0, 2))
         if win > 21:  # big windows: keep the CPU side in the millisecond range
             H, W, numD = min(H, 40), min(W, 120), min(numD, 12)
@@ -59,6 +62,12 @@ def main():
                 for _ in range(int(rng.integers(1, 4))):
                     y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
                     img[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 40))] = rng.integers(0, 256, 3).astype(np.uint8)
+        if rng.random() < 0.15:  # rows with padding: the C-ABI reads them through asw_image.step
+            pad = int(rng.integers(1, 9))
+            Lp = np.zeros((H, W + pad, 3), np.uint8)
+            Rp = np.full((H, W + pad, 3), 255, np.uint8)
+            Lp[:, :W], Rp[:, :W] = L, R
+            L, R = Lp[:, :W], Rp[:, :W]   # non-contiguous views; the oracle wrappers copy them
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
                                 "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
@@ -78,7 +87,9 @@ def main():
                 d, v = ctx.computeAdaptiveWeight_direct8(L, R, 0, win, minD, numD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
             elif method == "geodesic":
-                win = min(win, 15)
+                if win > 15:  # (win+2)^2 relaxations per pixel and pass on the CPU side: small frames
+                    L, R = np.ascontiguousarray(L[:20, :64]), np.ascontiguousarray(R[:20, :64])
+                    numD = min(numD, 8)
                 rc, dw, vw = O.asw_geodesic(L, R, dt, win, minD, numD, want_vol=True)
                 d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, win, minD, numD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
@@ -134,8 +145,10 @@ def main():
                 rc, dw = O.ncc_disparity(L, R, dt, win, minD, numD)
                 ok = np.array_equal(ctx.computeNCC(L, R, dt, win, minD, numD), dw)
             elif method == "ad_tad":
-                rc, vw = O.compute_ad(L, R, dt, minD, numD)
                 T = int(rng.integers(-5, 261))
+                if rng.integers(0, 3) == 0:  # 1-channel branch, M.cpp:264-291
+                    L, R = np.ascontiguousarray(L[:, :, 1]), np.ascontiguousarray(R[:, :, 2])
+                rc, vw = O.compute_ad(L, R, dt, minD, numD)
                 rc, tw = O.compute_tad(L, R, dt, T, minD, numD)
                 ok = (np.array_equal(np.stack(ctx.computeAD(L, R, dt, minD, numD)), vw) and
                       np.array_equal(np.stack(ctx.computeTAD(L, R, dt, T, minD, numD)), tw) and
@@ -150,7 +163,8 @@ def main():
                 rc, vw = O.cost_sad(L, R, dt, win, minD, numD)
                 ok = np.array_equal(np.stack(ctx.getCostSAD(L, R, dt, win, minD, numD)), vw)
             elif method == "geodist":
-                win = min(win, 15)
+                if win > 15:
+                    L = np.ascontiguousarray(L[:20, :64])
                 rc, vw = O.geodesic_dist(L, win, 3)
                 ok = np.array_equal(ctx.getGeodesicDist(L, win, 3), vw)
             elif method == "gfilter":
