@@ -151,3 +151,16 @@ def test_1080p_new_methods_properties(ctx):
     ctx.match_resident(2, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 64)
     d8 = ctx.download_disparity_u8(2, (360, 640), normalize=True)
     assert d8.dtype == np.uint8 and d8.min() == 0 and d8.max() == 255
+
+
+def test_batch_with_frames_of_different_shapes(ctx):
+    """The scheduler's two slots and the context's grow-only scratch are reused across frames: shapes that grow and shrink inside
+    one batch must not disturb the frames still in flight."""
+    shapes = [(40, 64), (96, 200), (17, 33), (120, 310), (8, 8), (64, 128), (121, 77)]
+    frames = [make_pair(h, w, 10, seed=200 + i)[:2] for i, (h, w) in enumerate(shapes)]
+    for alg in (A.ADAPTIVE_WEIGHT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, A.ADAPTIVE_WEIGHT_GUIDED_FILTER, A.ADAPTIVE_WEIGHT_GEODESIC):
+        for devs in ([0], [0, 0]):
+            outs = asw.stereoMatchingBatch([f[0] for f in frames], [f[1] for f in frames], LEFT, alg, 7, 0, 10, device_ids=devs)
+            for (L, R), o in zip(frames, outs):
+                assert o.shape == L.shape[:2]
+                assert np.array_equal(o, ctx.stereoMatching(L, R, LEFT, alg, 7, 0, 10)), (alg, L.shape)
