@@ -118,9 +118,8 @@ class Context:
 
     @staticmethod
     def _candidates(algorithm, numDisparity):
-        inclusive = algorithm in (StereoMatchingAlgorithms.ADAPTIVE_WEIGHT, StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_8DIRECT,
-                                  StereoMatchingAlgorithms.ADAPTIVE_WEIGHT_GEODESIC)
-        return numDisparity + (1 if inclusive else 0)
+        n = _lib.lib().asw_volume_planes(int(algorithm), int(numDisparity))  # the library knows which ranges are inclusive
+        return n if n > 0 else int(numDisparity)
 
     # ---- whole-method entry point (M.h:91-92) ----
     def stereoMatching(self, srcLeft, srcRight, disparityType, algorithmType, winSize=15, minDisparity=0,

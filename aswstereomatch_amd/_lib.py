@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "asw_cost_ncc", "asw_ncc_disparity",
     "asw_preprocess_pair", "asw_download_pair", "asw_download_disparity_u8",
     "asw_cost_ad", "asw_cost_tad", "asw_cost_sd", "asw_cost_similarity", "asw_cost_sad",
-    "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray", "asw_lr_check",
+    "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray", "asw_lr_check", "asw_volume_planes",
     "asw_stereo_match_batch",
 ]
 
@@ -95,6 +95,7 @@ def lib():
         l.asw_guided_filter.argtypes = [P, IMG, P, P, I, D]
         l.asw_geodesic_dist.argtypes = [P, IMG, P, I, I]
         l.asw_wta.argtypes = [P, P, I, I, I, I, P]
+        l.asw_volume_planes.argtypes = [I, I]
         l.asw_lr_check.argtypes = [P, P, P, I, I, C.c_float, C.c_float, P, P]
         l.asw_bgr2gray.argtypes = [P, IMG, P]
         l.asw_stereo_match_batch.argtypes = [I, IMG, IMG, IMG, I, I, I, I, I, I, C.POINTER(C.c_int)]

@@ -26,6 +26,26 @@ int match_host(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_
     return ASW_OK;
 }
 
+extern "C" int asw_volume_planes(int algorithm, int num_disparity)
+{
+    switch (algorithm) {
+    case ASW_ALG_ADAPTIVE_WEIGHT:            // offset <= max_offset, M.cpp:1021,1074
+    case ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT:    // M.cpp:1171
+    case ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC:   // M.cpp:1447,1467
+    case ASW_ALG_ADAPTIVE_WEIGHT_BILATERAL_GRID:  // M.cpp:2256,2280
+        return num_disparity + 1;
+    case ASW_ALG_ADAPTIVE_WEIGHT_BLO1:
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER:
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2:
+    case ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_3:
+    case ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN:
+    case ASW_ALG_NCC:
+        return num_disparity;
+    default:
+        return 0;
+    }
+}
+
 extern "C" int asw_stereo_match(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                 int disparity_type, int algorithm, int win_size, int min_disparity,
                                 int num_disparity, float* cost_volume_out)

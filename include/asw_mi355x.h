@@ -97,10 +97,15 @@ int asw_device_count(void);
  * (min_d + index), like the reference's CV_32FC1 result.  Per-method literals are the
  * selector's (gamma_c=30, gamma_g=20; eps=1e-6; rateS=rateR=10).
  * cost_volume_out (optional, may be NULL): aggregated cost volume, [n][rows][cols] f32 with
- * n = num_d (+1 for ADAPTIVE_WEIGHT, 8DIRECT and GEODESIC, whose range is inclusive, M.cpp:1021,1171,1447). */
+ * n = asw_volume_planes(algorithm, num_d): num_d, or num_d + 1 for ADAPTIVE_WEIGHT, 8DIRECT, GEODESIC and BILATERAL_GRID, whose
+ * candidate range is inclusive (M.cpp:1021,1074; 1171; 1447,1467; 2256,2280). */
 int asw_stereo_match(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                      int disparity_type, int algorithm, int win_size, int min_disparity, int num_disparity,
                      float* cost_volume_out);
+
+/* Planes of the cost volume `algorithm` produces for num_disparity candidates (what cost_volume_out must hold);
+ * 0 for an algorithm the library does not serve. */
+int asw_volume_planes(int algorithm, int num_disparity);
 
 /* ---- the same, split so that inputs can stay resident in HBM (bench / pipelines) ---- */
 int asw_upload_pair(asw_ctx* ctx, int slot, const asw_image* left, const asw_image* right);

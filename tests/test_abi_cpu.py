@@ -64,3 +64,12 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for needle in ("libasw_oracle", "asw_oracle", "from oracle", "import oracle", "oracle/"):
                     assert needle not in src.replace("CPU oracle under oracle/", ""), (f, needle)
+
+
+def test_volume_planes_is_a_pure_host_function():
+    # sizing rule of cost_volume_out (no GPU involved): inclusive candidate ranges have one more plane
+    from aswstereomatch_amd import _lib
+
+    l = _lib.lib()
+    assert [l.asw_volume_planes(a, 64) for a in range(12)] == [0, 0, 65, 65, 65, 65, 64, 64, 64, 64, 64, 64]
+    assert l.asw_volume_planes(99, 64) == 0

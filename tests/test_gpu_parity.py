@@ -474,6 +474,9 @@ def test_bilateral_grid_selector_and_errors(ctx, oracle):
     d = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, 15, 0, 5)   # rates 10, 10 (M.cpp:67)
     assert np.array_equal(d, oracle.asw_bilgrid(L, R, 0, 10, 10, 0, 5)[1])
     assert np.array_equal(d, oracle.stereo_matching(L, R, 0, 5, 15, 0, 5)[1])
+    d2, v2 = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_BILATERAL_GRID, 15, 0, 5, return_cost_volume=True)
+    assert v2.shape == (6, 40, 64) and np.array_equal(d2, d)   # inclusive range: numD + 1 planes (asw_volume_planes)
+    assert np.array_equal(v2, oracle.asw_bilgrid(L, R, 0, 10, 10, 0, 5, want_vol=True)[2], equal_nan=True)
     gray = oracle.bgr2gray(L), oracle.bgr2gray(R)
     assert np.array_equal(ctx.computeAdaptiveWeight_bilateralGrid(gray[0], gray[1], LEFT, 10, 10, 0, 5), d)  # 1-channel input
     with pytest.raises(asw.AswError) as e:   # the reference's RIGHT branch reads one past the image row

@@ -69,7 +69,7 @@ def main():
             Lp[:, :W], Rp[:, :W] = L, R
             L, R = Lp[:, :W], Rp[:, :W]   # non-contiguous views; the oracle wrappers copy them
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
-                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck"]))
+                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck", "resident"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
         if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
             ctx.close()
@@ -118,6 +118,23 @@ def main():
                 rc, dw, vw = O.asw_bilgrid(L, R, 0, sS, sR, minD, nD, want_vol=True)
                 d, v = ctx.computeAdaptiveWeight_bilateralGrid(L, R, 0, sS, sR, minD, nD, return_cost_volume=True)
                 ok = np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
+            elif method == "resident":
+                # the resident split (asw_upload_pair / asw_match_resident / asw_download_*) against the one-call entry point
+                alg = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11]))
+                w2 = win if win % 2 else win + 1
+                w2 = min(w2, 15)
+                dt2 = dt if alg in (2, 4, 6, 7, 9, 11) else 0
+                md = 0 if alg == 6 else minD
+                nD = min(numD, 16)
+                slot = int(rng.integers(0, 3))
+                keep = bool(rng.integers(0, 2)) and not (alg == 11 and dt2 == 1)  # computeNCC's RIGHT branch never forms a cost
+                want = ctx.stereoMatching(L, R, dt2, alg, w2, md, nD, return_cost_volume=keep)
+                ctx.upload_pair(slot, L, R)
+                ctx.match_resident(slot, dt2, alg, w2, md, nD, keep_volume=keep)
+                got = ctx.download_disparity(slot, L.shape[:2])
+                ok = np.array_equal(got, want[0] if keep else want)
+                if keep and alg != 11:
+                    ok = ok and np.array_equal(ctx.download_volume(slot, want[1].shape), want[1], equal_nan=True)
             elif method == "lrcheck":
                 a = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
                 b = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
