@@ -174,8 +174,9 @@ def main():
                 reg = float(rng.choice([0.4, 0.0, 1.0, 0.25]))
                 thc = float(rng.choice([10, 0, 254.5, 300, -1, 3.7]))
                 thg = float(rng.choice([50, 0, 0.5, 1e4, 12.3]))
-                rc, vw = O.compute_similarity(L, R, reg, thc, thg, 0, minD, numD)
-                ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, reg, thc, thg, 0, minD, numD)), vw)
+                wpad = win if rng.integers(0, 3) == 0 and win % 2 == 1 else None   # the padded overload, M.cpp:651-668
+                rc, vw = O.compute_similarity(L, R, reg, thc, thg, 0, minD, numD, win=wpad)
+                ok = np.array_equal(np.stack(ctx.computeSimilarity(L, R, reg, thc, thg, 0, minD, numD, winSize=wpad)), vw)
             elif method == "sad":
                 rc, vw = O.cost_sad(L, R, dt, win, minD, numD)
                 ok = np.array_equal(np.stack(ctx.getCostSAD(L, R, dt, win, minD, numD)), vw)
@@ -192,10 +193,17 @@ def main():
                 ok = close(q, qw)
             elif method == "prep":
                 dw_, dh_ = int(rng.integers(1, 2 * W + 2)), int(rng.integers(1, 2 * H + 2))
+                if rng.integers(0, 4) == 0 and H % 2 == 0 and W % 2 == 0:
+                    dw_, dh_ = W // 2, H // 2   # the exact 2x downscale resize() does with INTER_AREA
                 boost = bool(dt)
                 ok = bool(ctx.preprocess_pair(7, L, R, (dw_, dh_), detail_boost=boost))
                 gl, gr = ctx.download_pair(7, (dh_, dw_, 3))
                 ok = ok and np.array_equal(gl, O.preprocess(L, (dw_, dh_), boost)) and np.array_equal(gr, O.preprocess(R, (dw_, dh_), boost))
+                if ok and dw_ >= 4 and dh_ >= 2:  # match on the processed pair, 8-bit map as the driver writes it (main.cpp:97-98)
+                    nrm = bool(rng.integers(0, 2))
+                    ctx.match_resident(7, 0, 3, 5, 0, 6)
+                    d8 = ctx.download_disparity_u8(7, (dh_, dw_), normalize=nrm)
+                    ok = np.array_equal(d8, O.disparity_to_u8(ctx.download_disparity(7, (dh_, dw_)), nrm))
             else:
                 rc, vw = O.cost_ncc(L, R, dt, win, minD, numD)
                 ok = np.array_equal(np.stack(ctx.computeNCC_costs(L, R, dt, win, minD, numD)), vw, equal_nan=True)
