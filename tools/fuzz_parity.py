@@ -69,7 +69,7 @@ def main():
             Lp[:, :W], Rp[:, :W] = L, R
             L, R = Lp[:, :W], Rp[:, :W]   # non-contiguous views; the oracle wrappers copy them
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
-                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck", "resident"]))
+                                "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck", "resident", "batch"]))
         tag = (method, H, W, win, minD, numD, dt, seed)
         if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
             ctx.close()
@@ -135,6 +135,20 @@ def main():
                 ok = np.array_equal(got, want[0] if keep else want)
                 if keep and alg != 11:
                     ok = ok and np.array_equal(ctx.download_volume(slot, want[1].shape), want[1], equal_nan=True)
+            elif method == "batch":
+                # the frame scheduler: a few frames of different shapes, one to three scheduler threads on the device
+                alg = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11]))
+                w2 = min(win if win % 2 else win + 1, 15)
+                dt2 = dt if alg in (2, 4, 6, 7, 9, 11) else 0
+                md = 0 if alg == 6 else minD
+                nD = min(numD, 12)
+                fr = []
+                for q in range(int(rng.integers(1, 6))):
+                    hq, wq = int(rng.integers(1, 60)), int(rng.integers(1, 160))
+                    fr.append(make_pair(hq, wq, 4, seed=seed + q, block=8)[:2])
+                devs = [0] * int(rng.integers(1, 4))
+                outs = asw.stereoMatchingBatch([f[0] for f in fr], [f[1] for f in fr], dt2, alg, w2, md, nD, device_ids=devs)
+                ok = all(np.array_equal(o, ctx.stereoMatching(f[0], f[1], dt2, alg, w2, md, nD)) for f, o in zip(fr, outs))
             elif method == "lrcheck":
                 a = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
                 b = rng.integers(-2, numD + 3, (H, W)).astype(np.float32)
