@@ -22,7 +22,7 @@ from ._lib import AswError, AswImage, AswTiming
 
 __all__ = [
     "DisparityType", "StereoMatchingAlgorithms", "DISPARITY_LEFT", "DISPARITY_RIGHT", "Context",
-    "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "computeAdaptiveWeight",
+    "stereoMatching", "computeAD", "computeTAD", "computeSimilarity", "getCostSAD", "getCostSAD_d", "computeAdaptiveWeight",
     "computeAdaptiveWeight_geodesic", "getGeodesicDist", "getGuidedFilter", "computeAdaptiveWeight_GuidedF",
     "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_WeightedMedian", "winnerTakeAll", "last_status",
     "stereoMatchingBatch", "computeAdaptiveWeight_BLO1", "computeAdaptiveWeight_direct8", "computeNCC", "computeNCC_costs",
@@ -134,7 +134,7 @@ class Context:
             vol = np.zeros((self._candidates(int(algorithmType), numDisparity), la.shape[0], la.shape[1]), np.float32)
             pv = vol.ctypes.data_as(C.c_void_p)
         rc = self._lib.asw_stereo_match(self._h, C.byref(li), C.byref(ri), C.byref(di), int(disparityType),
-                                        int(algorithmType), winSize, minDisparity, numDisparity, pv)
+                                        int(algorithmType), winSize, minDisparity, numDisparity, pv, 0 if vol is None else vol.size)
         if not self._finish(rc, "asw_stereo_match"):
             return (None, None) if return_cost_volume else None
         return (disp, vol) if return_cost_volume else disp
@@ -148,7 +148,7 @@ class Context:
         if return_cost_volume:
             vol = np.zeros((n_vol, la.shape[0], la.shape[1]), np.float32)
             pv = vol.ctypes.data_as(C.c_void_p)
-        rc = fn(self._h, C.byref(li), C.byref(ri), C.byref(di), *args, pv)
+        rc = fn(self._h, C.byref(li), C.byref(ri), C.byref(di), *args, pv, 0 if vol is None else vol.size)
         if not self._finish(rc, name):
             return (None, None) if return_cost_volume else None
         return (disp, vol) if return_cost_volume else disp
@@ -265,6 +265,17 @@ class Context:
         return self._cost(self._lib.asw_cost_sad, "asw_cost_sad", leftImg, rightImg, np.float32, a.shape[:2], numDisparity,
                           (int(dispType), winSize, minDisparity, numDisparity))
 
+    def getCostSAD_d(self, leftImg, rightImg, disparity, dispType=DISPARITY_LEFT, winSize=35):
+        """getCostSAD_d as declared (M.h:156, M.cpp:2442-2503): one disparity, the non-reference view already bordered by
+        the caller (M.cpp:2877-2878).  None where the reference returns Mat()."""
+        li, la = _image(leftImg)
+        ri, ra = _image(rightImg)
+        ref = la if int(dispType) == 0 else ra
+        out = np.zeros(ref.shape[:2], np.float32)
+        rc = self._lib.asw_cost_sad_d(self._h, C.byref(li), C.byref(ri), out.ctypes.data_as(C.c_void_p), int(disparity),
+                                      int(dispType), winSize)
+        return out if self._finish(rc, "asw_cost_sad_d") else None
+
     # ---- public building blocks ----
     def getGuidedFilter(self, guidedImg, inputP, r, eps):
         gi, ga = _image(guidedImg)
@@ -311,26 +322,33 @@ class Context:
         self._finish(rc, "asw_bgr2gray")
         return out
 
-    # ---- resident (HBM) API used by bench.py ----
+    # ---- resident (HBM) API used by bench.py.  The reference has no equivalent whose silent returns could be mimicked:
+    # every non-zero status raises AswError (a rejected upload or a failed match also empties the slot's results, so a
+    # later download cannot hand back another frame's disparity) ----
+    def _strict(self, rc, where):
+        _state.status = rc
+        if rc != 0:
+            raise AswError(rc, where)
+
     def upload_pair(self, slot, left, right):
         li, la = _image(left)
         ri, ra = _image(right)
-        self._finish(self._lib.asw_upload_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_upload_pair")
+        self._strict(self._lib.asw_upload_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_upload_pair")
 
     def match_resident(self, slot, disparityType, algorithmType, winSize, minDisparity, numDisparity, keep_volume=False):
         rc = self._lib.asw_match_resident(self._h, slot, int(disparityType), int(algorithmType), winSize, minDisparity,
                                           numDisparity, 1 if keep_volume else 0)
-        self._finish(rc, "asw_match_resident")
+        self._strict(rc, "asw_match_resident")
 
     def download_disparity(self, slot, shape):
         disp = np.zeros(shape, np.float32)
         di, _ = _image(disp, 5)
-        self._finish(self._lib.asw_download_disparity(self._h, slot, C.byref(di)), "asw_download_disparity")
+        self._strict(self._lib.asw_download_disparity(self._h, slot, C.byref(di)), "asw_download_disparity")
         return disp
 
     def download_volume(self, slot, shape):
         vol = np.zeros(shape, np.float32)
-        self._finish(self._lib.asw_download_volume(self._h, slot, vol.ctypes.data_as(C.c_void_p), vol.size), "asw_download_volume")
+        self._strict(self._lib.asw_download_volume(self._h, slot, vol.ctypes.data_as(C.c_void_p), vol.size), "asw_download_volume")
         return vol
 
     # ---- driver-side pre/post-processing on the device (aswStereoMatch.cpp:30-31, 67-89, 97-98) ----
@@ -341,7 +359,8 @@ class Context:
         ri, ra = _image(right_full)
         rc = self._lib.asw_preprocess_pair(self._h, slot, C.byref(li), C.byref(ri), int(dsize[0]), int(dsize[1]),
                                            1 if detail_boost else 0)
-        return self._finish(rc, "asw_preprocess_pair")
+        self._strict(rc, "asw_preprocess_pair")
+        return True
 
     def download_pair(self, slot, shape):
         """The resident 8U pair of `slot` (e.g. after preprocess_pair); shape = (rows, cols, channels)."""
@@ -349,14 +368,14 @@ class Context:
         right = np.zeros(shape, np.uint8)
         li, _ = _image(left)
         ri, _ = _image(right)
-        self._finish(self._lib.asw_download_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_download_pair")
+        self._strict(self._lib.asw_download_pair(self._h, slot, C.byref(li), C.byref(ri)), "asw_download_pair")
         return left, right
 
     def download_disparity_u8(self, slot, shape, normalize=True):
         """disparityMap.convertTo(CV_8UC1) [+ normalize(0, 255, NORM_MINMAX)] of the last match of `slot` (main.cpp:97-98)."""
         out = np.zeros(shape, np.uint8)
         oi, _ = _image(out)
-        self._finish(self._lib.asw_download_disparity_u8(self._h, slot, C.byref(oi), 1 if normalize else 0),
+        self._strict(self._lib.asw_download_disparity_u8(self._h, slot, C.byref(oi), 1 if normalize else 0),
                      "asw_download_disparity_u8")
         return out
 
@@ -433,6 +452,7 @@ computeAD = _bind("computeAD")
 computeTAD = _bind("computeTAD")
 computeSimilarity = _bind("computeSimilarity")
 getCostSAD = _bind("getCostSAD")
+getCostSAD_d = _bind("getCostSAD_d")
 computeAdaptiveWeight = _bind("computeAdaptiveWeight")
 computeAdaptiveWeight_direct8 = _bind("computeAdaptiveWeight_direct8")
 computeAdaptiveWeight_GuidedF_3 = _bind("computeAdaptiveWeight_GuidedF_3")

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "asw_aggregate_wmedian", "asw_aggregate_blo1", "asw_aggregate_bilgrid", "asw_aggregate_direct8", "asw_aggregate_guided3",
     "asw_cost_ncc", "asw_ncc_disparity",
     "asw_preprocess_pair", "asw_download_pair", "asw_download_disparity_u8",
-    "asw_cost_ad", "asw_cost_tad", "asw_cost_sd", "asw_cost_similarity", "asw_cost_sad",
+    "asw_cost_ad", "asw_cost_tad", "asw_cost_sd", "asw_cost_similarity", "asw_cost_sad", "asw_cost_sad_d",
     "asw_guided_filter", "asw_geodesic_dist", "asw_wta", "asw_bgr2gray", "asw_lr_check", "asw_volume_planes",
     "asw_stereo_match_batch",
 ]
@@ -66,32 +66,33 @@ def lib():
         I = C.c_int
         D = C.c_double
         IMG = C.POINTER(AswImage)
-        l.asw_stereo_match.argtypes = [P, IMG, IMG, IMG, I, I, I, I, I, P]
+        l.asw_stereo_match.argtypes = [P, IMG, IMG, IMG, I, I, I, I, I, P, C.c_size_t]
         l.asw_upload_pair.argtypes = [P, I, IMG, IMG]
         l.asw_match_resident.argtypes = [P, I, I, I, I, I, I, I]
         l.asw_download_disparity.argtypes = [P, I, IMG]
         l.asw_download_volume.argtypes = [P, I, P, C.c_size_t]
         l.asw_synchronize.argtypes = [P]
         l.asw_get_timing.argtypes = [P, C.POINTER(AswTiming)]
-        l.asw_aggregate_bilateral.argtypes = [P, IMG, IMG, IMG, D, D, I, I, I, I, P]
-        l.asw_aggregate_geodesic.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P]
-        l.asw_aggregate_direct8.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P]
-        l.asw_aggregate_guided3.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
+        l.asw_aggregate_bilateral.argtypes = [P, IMG, IMG, IMG, D, D, I, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_geodesic.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_direct8.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_guided3.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P, C.c_size_t]
         l.asw_cost_ncc.argtypes = [P, IMG, IMG, P, I, I, I, I, I]
         l.asw_ncc_disparity.argtypes = [P, IMG, IMG, IMG, I, I, I, I]
         l.asw_preprocess_pair.argtypes = [P, I, IMG, IMG, I, I, I]
         l.asw_download_pair.argtypes = [P, I, IMG, IMG]
         l.asw_download_disparity_u8.argtypes = [P, I, IMG, I]
-        l.asw_aggregate_guided.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
-        l.asw_aggregate_guided2.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
-        l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P]
-        l.asw_aggregate_blo1.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P]
-        l.asw_aggregate_bilgrid.argtypes = [P, IMG, IMG, IMG, I, D, D, I, I, P]
+        l.asw_aggregate_guided.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_guided2.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_wmedian.argtypes = [P, IMG, IMG, IMG, I, I, D, D, I, I, P, C.c_size_t]
+        l.asw_aggregate_blo1.argtypes = [P, IMG, IMG, IMG, I, D, I, I, I, P, C.c_size_t]
+        l.asw_aggregate_bilgrid.argtypes = [P, IMG, IMG, IMG, I, D, D, I, I, P, C.c_size_t]
         l.asw_cost_ad.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_cost_sd.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_cost_tad.argtypes = [P, IMG, IMG, P, I, I, I, I]
         l.asw_cost_similarity.argtypes = [P, IMG, IMG, P, D, D, D, I, I, I, I]
         l.asw_cost_sad.argtypes = [P, IMG, IMG, P, I, I, I, I]
+        l.asw_cost_sad_d.argtypes = [P, IMG, IMG, P, I, I, I]
         l.asw_guided_filter.argtypes = [P, IMG, P, P, I, D]
         l.asw_geodesic_dist.argtypes = [P, IMG, P, I, I]
         l.asw_wta.argtypes = [P, P, I, I, I, I, P]

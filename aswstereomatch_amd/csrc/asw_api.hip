@@ -11,18 +11,27 @@
 #include "asw_internal.h"
 #include "asw_host.h"
 
+// Host buffers in, host buffers out.  Works on the context's private frame: the caller's resident slots (asw_upload_pair /
+// asw_match_resident) are never touched by a one-call entry point.
 int match_host(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp, int algorithm,
-                      const MatchParams& mp, float* cost_volume_out)
+                      const MatchParams& mp, float* cost_volume_out, size_t cost_volume_floats)
 {
     if (!ctx) return ASW_ERR_BAD_ARGUMENT;
     ASW_TRY(check_pair(left, right));
     ASW_TRY(check_disp_out(disp, left->rows, left->cols));
-    const int slot = 0;
-    ASW_TRY(asw_upload_pair(ctx, slot, left, right));
-    Frame* f = frame_slot(ctx, slot, false);
+    if (cost_volume_out) {  // the caller states what its buffer holds; a short one is refused before anything is written
+        const int planes = asw_volume_planes(algorithm, mp.numD);
+        if (planes > 0 && cost_volume_floats < (size_t)planes * left->rows * left->cols) return ASW_ERR_BAD_ARGUMENT;
+    }
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    Frame* f = &ctx->host_frame;
+    ASW_TRY(upload_pair_into(ctx, f, left, right));
     ASW_TRY(run_method(ctx, f, algorithm, mp, cost_volume_out != nullptr));
-    ASW_TRY(asw_download_disparity(ctx, slot, disp));
-    if (cost_volume_out) ASW_TRY(asw_download_volume(ctx, slot, cost_volume_out, f->vol_floats));
+    ASW_TRY(download_disparity_from(ctx, f, disp));
+    if (cost_volume_out) {
+        if (f->vol_floats > cost_volume_floats) return ASW_ERR_BAD_ARGUMENT;
+        ASW_TRY(download_volume_from(ctx, f, cost_volume_out, f->vol_floats));
+    }
     return ASW_OK;
 }
 
@@ -48,30 +57,30 @@ extern "C" int asw_volume_planes(int algorithm, int num_disparity)
 
 extern "C" int asw_stereo_match(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                 int disparity_type, int algorithm, int win_size, int min_disparity,
-                                int num_disparity, float* cost_volume_out)
+                                int num_disparity, float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
-    return match_host(ctx, left, right, disp, algorithm, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, algorithm, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_aggregate_bilateral(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                        double gamma_c, double gamma_g, int disparity_type, int win_size,
-                                       int min_disparity, int num_disparity, float* cost_volume_out)
+                                       int min_disparity, int num_disparity, float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
     mp.gamma_c = gamma_c; mp.gamma_g = gamma_g;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_aggregate_direct8(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, int win_size, int min_disparity, int num_disparity,
-                                     float* cost_volume_out)
+                                     float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_8DIRECT, mp, cost_volume_out, cost_volume_floats);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -179,20 +188,20 @@ extern "C" int asw_lr_check(asw_ctx* ctx, const float* disp_left, const float* d
 
 extern "C" int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                     int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                                    float* cost_volume_out)
+                                    float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_aggregate_guided2(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                                     float* cost_volume_out)
+                                     float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_2, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_cost_similarity(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost,
@@ -262,6 +271,56 @@ extern "C" int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image
     return ASW_OK;
 }
 
+// getCostSAD_d (M.cpp:2442-2503) as the reference declares it: one disparity, the other view pre-bordered by the caller
+extern "C" int asw_cost_sad_d(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity,
+                              int disparity_type, int win_size)
+{
+    if (!ctx || !cost) return ASW_ERR_BAD_ARGUMENT;
+    ASW_TRY(check_u8_image(left));
+    ASW_TRY(check_u8_image(right));
+    if ((left->channels != 1 && left->channels != 3) || (right->channels != 1 && right->channels != 3)) return ASW_ERR_UNSUPPORTED_LAYOUT;
+    if (win_size % 2 == 0) return ASW_ERR_EVEN_WINDOW;  // M.cpp:2458-2462
+    if (win_size < 1 || win_size > 128) return ASW_ERR_BAD_ARGUMENT;
+    if (disparity_type != ASW_DISPARITY_LEFT && disparity_type != ASW_DISPARITY_RIGHT) return ASW_ERR_BAD_ARGUMENT;
+    const bool lref = disparity_type == ASW_DISPARITY_LEFT;
+    const asw_image* ref = lref ? left : right;   // the view the cost plane belongs to
+    const asw_image* bord = lref ? right : left;  // the bordered (wider) other view
+    if (ref->rows != bord->rows) return ASW_ERR_BAD_ARGUMENT;  // absdiff of unequal sizes throws in the reference
+    const int H = ref->rows, W = ref->cols, Wb = bord->cols;
+    if (Wb <= W) return ASW_ERR_SIZE_MISMATCH;  // M.cpp:2473-2476 / 2488-2491: return Mat()
+    const int x0 = lref ? Wb - W - disparity : disparity;  // M.cpp:2478 / 2493
+    if (x0 < 0 || x0 + W > Wb) return ASW_ERR_BAD_ARGUMENT;
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf& dref = ctx->buf("stageL");
+    DevBuf& dbord = ctx->buf("stageR");
+    DevBuf& gref = ctx->buf("grayL");
+    DevBuf& gbord = ctx->buf("sadd_gray_wide");
+    DevBuf& gcrop = ctx->buf("grayR");
+    DevBuf& raw = ctx->buf("g_raw");
+    ASW_TRY(upload_image(ctx, ref, dref));
+    ASW_TRY(upload_image(ctx, bord, dbord));
+    ASW_TRY(gref.ensure((size_t)H * W));
+    ASW_TRY(gbord.ensure((size_t)H * Wb));
+    ASW_TRY(gcrop.ensure((size_t)H * W));
+    ASW_TRY(raw.ensure((size_t)H * W * 4));
+    const uint8_t* pref = dref.as<uint8_t>();
+    const uint8_t* pbord = dbord.as<uint8_t>();
+    if (ref->channels == 3) {  // M.cpp:2446-2456
+        ASW_TRY(launch_bgr2gray(ctx->stream, pref, H, W, gref.as<uint8_t>()));
+        pref = gref.as<uint8_t>();
+    }
+    if (bord->channels == 3) {
+        ASW_TRY(launch_bgr2gray(ctx->stream, pbord, H, Wb, gbord.as<uint8_t>()));
+        pbord = gbord.as<uint8_t>();
+    }
+    // the ROI of the bordered view as a dense plane; then |ref - roi| -> f32 -> boxFilter mean is launch_cost_sad at offset 0
+    ASW_HIP_TRY(hipMemcpy2DAsync(gcrop.p, (size_t)W, pbord + x0, (size_t)Wb, (size_t)W, H, hipMemcpyDeviceToDevice, ctx->stream));
+    ASW_TRY(launch_cost_sad(ctx->stream, pref, gcrop.as<uint8_t>(), H, W, ASW_DISPARITY_LEFT, win_size, 0, 1, raw.as<float>()));
+    ASW_HIP_TRY(hipMemcpyAsync(cost, raw.p, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ASW_OK;
+}
+
 extern "C" int asw_cost_ncc(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity_type,
                             int win_size, int min_disparity, int num_disparity, int normalized)
 {
@@ -300,16 +359,16 @@ extern "C" int asw_ncc_disparity(asw_ctx* ctx, const asw_image* left, const asw_
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
-    return match_host(ctx, left, right, disp, ASW_ALG_NCC, mp, nullptr);
+    return match_host(ctx, left, right, disp, ASW_ALG_NCC, mp, nullptr, 0);
 }
 
 extern "C" int asw_aggregate_guided3(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                                     float* cost_volume_out)
+                                     float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity; mp.eps = eps;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_3, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GUIDED_FILTER_3, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const float* p, float* q, int r, double eps)
@@ -361,11 +420,11 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
 
 extern "C" int asw_aggregate_geodesic(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                       int disparity_type, int win_size, int min_disparity, int num_disparity,
-                                      float* cost_volume_out)
+                                      float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_GEODESIC, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_geodesic_dist(asw_ctx* ctx, const asw_image* img, float* out, int win_size, int iter_time)
@@ -396,30 +455,30 @@ extern "C" int asw_geodesic_dist(asw_ctx* ctx, const asw_image* img, float* out,
 
 extern "C" int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                   int disparity_type, double sample_rate_r, int win_size, int min_disparity,
-                                  int num_disparity, float* cost_volume_out)
+                                  int num_disparity, float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
     mp.blo_rate_r = sample_rate_r;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BLO1, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BLO1, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_aggregate_bilgrid(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, double sample_rate_s, double sample_rate_r, int min_disparity,
-                                     int num_disparity, float* cost_volume_out)
+                                     int num_disparity, float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = 1; mp.minD = min_disparity; mp.numD = num_disparity;
     mp.grid_rate_s = sample_rate_s; mp.grid_rate_r = sample_rate_r;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BILATERAL_GRID, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_BILATERAL_GRID, mp, cost_volume_out, cost_volume_floats);
 }
 
 extern "C" int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                                      int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,
-                                     int num_disparity, float* cost_volume_out)
+                                     int num_disparity, float* cost_volume_out, size_t cost_volume_floats)
 {
     MatchParams mp;
     mp.disparity_type = disparity_type; mp.win = win_size; mp.minD = min_disparity; mp.numD = num_disparity;
     mp.rate_s = rate_s; mp.rate_r = rate_r;
-    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN, mp, cost_volume_out);
+    return match_host(ctx, left, right, disp, ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN, mp, cost_volume_out, cost_volume_floats);
 }

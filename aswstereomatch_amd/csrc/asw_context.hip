@@ -99,6 +99,7 @@ extern "C" void asw_destroy(asw_ctx* ctx)
     for (auto& f : ctx->frames) {
         f.L.release(); f.R.release(); f.disp.release(); f.vol.release();
     }
+    ctx->host_frame.L.release(); ctx->host_frame.R.release(); ctx->host_frame.disp.release(); ctx->host_frame.vol.release();
     for (auto& kv : ctx->scratch) kv.second.release();
     ctx->bil.taps.release();
     ctx->bil.lut.release();
@@ -173,20 +174,30 @@ Frame* frame_slot(asw_ctx* ctx, int slot, bool create)
     return &ctx->frames[slot];
 }
 
-extern "C" int asw_upload_pair(asw_ctx* ctx, int slot, const asw_image* left, const asw_image* right)
+// uploads a checked pair into `f`; whatever `f` held before (pair, disparity, volume) is gone, also when the upload fails
+int upload_pair_into(asw_ctx* ctx, Frame* f, const asw_image* left, const asw_image* right)
 {
-    if (!ctx) return ASW_ERR_BAD_ARGUMENT;
-    ASW_TRY(check_pair(left, right));
-    ASW_HIP_TRY(hipSetDevice(ctx->device));
-    Frame* f = frame_slot(ctx, slot, true);
-    if (!f) return ASW_ERR_BAD_ARGUMENT;
     f->valid = false;
+    f->invalidate_results();
     ASW_TRY(upload_image(ctx, left, f->L));
     ASW_TRY(upload_image(ctx, right, f->R));
     f->rows = left->rows; f->cols = left->cols; f->channels = left->channels;
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host buffers are caller-owned: done with them on return
     f->valid = true;
     return ASW_OK;
+}
+
+extern "C" int asw_upload_pair(asw_ctx* ctx, int slot, const asw_image* left, const asw_image* right)
+{
+    if (!ctx) return ASW_ERR_BAD_ARGUMENT;
+    Frame* f = frame_slot(ctx, slot, true);
+    if (!f) return ASW_ERR_BAD_ARGUMENT;
+    // a rejected pair leaves no stale pair behind either: the slot is empty until a pair has been accepted
+    f->valid = false;
+    f->invalidate_results();
+    ASW_TRY(check_pair(left, right));
+    ASW_HIP_TRY(hipSetDevice(ctx->device));
+    return upload_pair_into(ctx, f, left, right);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -260,6 +271,7 @@ extern "C" int asw_preprocess_pair(asw_ctx* ctx, int slot, const asw_image* left
     Frame* f = frame_slot(ctx, slot, true);
     if (!f) return ASW_ERR_BAD_ARGUMENT;
     f->valid = false;
+    f->invalidate_results();
     ASW_TRY(prep_one(ctx, left_full, out_width, out_height, detail_boost, f->L));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused for the right image
     ASW_TRY(prep_one(ctx, right_full, out_width, out_height, detail_boost, f->R));
@@ -289,7 +301,7 @@ extern "C" int asw_download_disparity_u8(asw_ctx* ctx, int slot, asw_image* disp
 {
     if (!ctx || !disp_u8 || !disp_u8->data) return ASW_ERR_BAD_ARGUMENT;
     Frame* f = frame_slot(ctx, slot, false);
-    if (!f || !f->valid || !f->disp.p) return ASW_ERR_NO_FRAME;
+    if (!f || !f->valid || !f->has_disp || !f->disp.p || f->disp_rows != f->rows || f->disp_cols != f->cols) return ASW_ERR_NO_FRAME;
     if (disp_u8->depth != ASW_8U || disp_u8->channels != 1 || disp_u8->rows != f->rows || disp_u8->cols != f->cols ||
         disp_u8->step < (size_t)f->cols)
         return ASW_ERR_BAD_ARGUMENT;
@@ -306,11 +318,9 @@ extern "C" int asw_download_disparity_u8(asw_ctx* ctx, int slot, asw_image* disp
     return ASW_OK;
 }
 
-extern "C" int asw_download_disparity(asw_ctx* ctx, int slot, asw_image* disp)
+int download_disparity_from(asw_ctx* ctx, Frame* f, asw_image* disp)
 {
-    if (!ctx) return ASW_ERR_BAD_ARGUMENT;
-    Frame* f = frame_slot(ctx, slot, false);
-    if (!f || !f->valid || !f->disp.p) return ASW_ERR_NO_FRAME;
+    if (!f || !f->valid || !f->has_disp || !f->disp.p || f->disp_rows != f->rows || f->disp_cols != f->cols) return ASW_ERR_NO_FRAME;
     ASW_TRY(check_disp_out(disp, f->rows, f->cols));
     ASW_HIP_TRY(hipSetDevice(ctx->device));
     ASW_HIP_TRY(hipMemcpy2DAsync(disp->data, disp->step, f->disp.p, (size_t)f->cols * 4, (size_t)f->cols * 4, f->rows,
@@ -319,15 +329,25 @@ extern "C" int asw_download_disparity(asw_ctx* ctx, int slot, asw_image* disp)
     return ASW_OK;
 }
 
-extern "C" int asw_download_volume(asw_ctx* ctx, int slot, float* out, size_t n_floats)
+extern "C" int asw_download_disparity(asw_ctx* ctx, int slot, asw_image* disp)
 {
-    if (!ctx || !out) return ASW_ERR_BAD_ARGUMENT;
-    Frame* f = frame_slot(ctx, slot, false);
-    if (!f || !f->valid || !f->vol.p || f->vol_floats == 0) return ASW_ERR_NO_FRAME;
+    if (!ctx) return ASW_ERR_BAD_ARGUMENT;
+    return download_disparity_from(ctx, frame_slot(ctx, slot, false), disp);
+}
+
+int download_volume_from(asw_ctx* ctx, Frame* f, float* out, size_t n_floats)
+{
+    if (!f || !f->valid || !f->has_disp || !f->vol.p || f->vol_floats == 0) return ASW_ERR_NO_FRAME;
     if (n_floats != f->vol_floats) return ASW_ERR_BAD_ARGUMENT;
     ASW_HIP_TRY(hipSetDevice(ctx->device));
     ASW_HIP_TRY(hipMemcpyAsync(out, f->vol.p, n_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
+}
+
+extern "C" int asw_download_volume(asw_ctx* ctx, int slot, float* out, size_t n_floats)
+{
+    if (!ctx || !out) return ASW_ERR_BAD_ARGUMENT;
+    return download_volume_from(ctx, frame_slot(ctx, slot, false), out, n_floats);
 }
 

@@ -25,6 +25,9 @@ int check_pair(const asw_image* L, const asw_image* R);
 int upload_image(asw_ctx* ctx, const asw_image* im, DevBuf& dst);
 int check_disp_out(const asw_image* d, int rows, int cols);
 Frame* frame_slot(asw_ctx* ctx, int slot, bool create);
+int upload_pair_into(asw_ctx* ctx, Frame* f, const asw_image* left, const asw_image* right);
+int download_disparity_from(asw_ctx* ctx, Frame* f, asw_image* disp);
+int download_volume_from(asw_ctx* ctx, Frame* f, float* out, size_t n_floats);
 int build_similarity_volume(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int W, int minD, int numD,
                                    double regularity, double thresC, double thresG, float* cost,
                                    uint32_t* ord_scratch = nullptr, float2* scales = nullptr);
@@ -33,4 +36,4 @@ int run_ncc_cost(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int 
                         int channels = 3);
 int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume, bool sync = true);
 int match_host(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp, int algorithm,
-                      const MatchParams& mp, float* cost_volume_out);
+                      const MatchParams& mp, float* cost_volume_out, size_t cost_volume_floats);

@@ -37,6 +37,12 @@ struct Frame {
     DevBuf vol;   // f32 aggregated cost volume of the last match (if kept)
     size_t vol_floats = 0;
     bool valid = false;
+    // the disparity (and volume) in `disp` / `vol` belong to the CURRENT pair: set by a successful match, cleared by every
+    // upload / pre-processing into the slot and by a failed match, so a download can never return another frame's result
+    // or read a smaller, older allocation
+    bool has_disp = false;
+    int disp_rows = 0, disp_cols = 0;
+    void invalidate_results() { has_disp = false; disp_rows = disp_cols = 0; vol_floats = 0; }
 };
 
 struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
@@ -53,7 +59,8 @@ struct asw_ctx {
     int device = 0;
     int prep_ntaps = 0;  // taps of the pre-processing bilateral filter (tables in buf("prep_tables"))
     hipStream_t stream = nullptr;
-    std::vector<Frame> frames;
+    std::vector<Frame> frames;  // resident slots of asw_upload_pair / asw_match_resident (caller-numbered)
+    Frame host_frame;           // private frame of the host-buffer entry points (asw_stereo_match, asw_aggregate_*): never a slot
     std::map<std::string, DevBuf> scratch;  // named grow-only scratch buffers
     BilateralTables bil;
     // weighted-median tables: exp() LUT of the colour weight per rateR, space kernel per (win, rateS)

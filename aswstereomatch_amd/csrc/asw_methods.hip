@@ -548,6 +548,7 @@ static int run_bilgrid(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
 
 int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, bool keep_volume, bool sync)
 {
+    f->invalidate_results();  // whatever the slot's disparity / volume were, they are not this call's
     if (mp.numD <= 0 || mp.minD < 0) return ASW_ERR_BAD_ARGUMENT;
     ASW_HIP_TRY(hipSetDevice(ctx->device));
     ASW_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -565,9 +566,17 @@ int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, boo
     case ASW_ALG_ADAPTIVE_WEIGHT_MEDIAN: rc = run_wmedian(ctx, f, mp, keep_volume); break;
     default: rc = ASW_ERR_UNSUPPORTED_METHOD; break;
     }
-    if (rc != ASW_OK) return rc;
+    if (rc != ASW_OK) {
+        f->invalidate_results();
+        return rc;
+    }
+    const size_t kept_floats = f->vol_floats;
+    f->vol_floats = 0;  // restored together with has_disp once nothing can fail any more
     ASW_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (!sync) return ASW_OK;  // pipelined callers (batch scheduler) order and wait on the stream themselves
+    if (!sync) {  // pipelined callers (batch scheduler) order and wait on the stream themselves
+        f->has_disp = true; f->disp_rows = f->rows; f->disp_cols = f->cols; f->vol_floats = kept_floats;
+        return ASW_OK;
+    }
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     float t = 0;
     ASW_HIP_TRY(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
@@ -575,6 +584,7 @@ int run_method(asw_ctx* ctx, Frame* f, int algorithm, const MatchParams& mp, boo
     ASW_HIP_TRY(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
     ctx->timing.aggregate_ms = t;
     ctx->timing.cost_ms = ctx->timing.total_ms - ctx->timing.aggregate_ms;
+    f->has_disp = true; f->disp_rows = f->rows; f->disp_cols = f->cols; f->vol_floats = kept_floats;
     return ASW_OK;
 }
 
@@ -599,6 +609,7 @@ int asw_internal_stage_slot(asw_ctx* ctx, int slot, int rows, int cols, int chan
     ASW_TRY(f->R.ensure(bytes));
     ASW_TRY(f->disp.ensure((size_t)rows * cols * 4));
     f->rows = rows; f->cols = cols; f->channels = channels; f->valid = true;
+    f->invalidate_results();
     *out = f;
     return ASW_OK;
 }

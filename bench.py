@@ -7,6 +7,13 @@ A "step" is one pass of the hot path over one batch of `--frames` stereo pairs t
 resident in HBM (uploaded before the timed region).  One process per GPU; frames are independent,
 so ranks never exchange data: torch.distributed is used only for the barrier around the
 timed region and the MAX over ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+
+N > 1: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` every process is one
+rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); a bare `python bench.py --gpus N` starts the N
+ranks itself as child processes (launch_ranks: the parent never touches the GPU).  Either way WORLD_SIZE
+must equal --gpus and every rank must find its own GPU, or the run fails loudly.  After the timed region
+rank 0 also drives all N devices from one process through the library's own batch API
+(`asw_stereo_match_batch`, 64 frames, host buffers in and out) and reports it as `batch_api`.
 """
 import argparse
 import json
@@ -110,7 +117,7 @@ def cpu_baseline(args, L, R, gpu_disp, alg):
                       % (reps, sw, sh, D, win, rc, cores, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -121,52 +128,176 @@ def main():
     ap.add_argument("--disp", type=int, default=128)
     ap.add_argument("--win", type=int, default=15)
     ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step (C5: 64 frames / 8 GPUs)")
+    ap.add_argument("--batch-frames", type=int, default=64,
+                    help="frames of the asw_stereo_match_batch leg over all --gpus devices (C5: 64); 0 skips it")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
-    args = ap.parse_args()
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal only: allow more ranks than visible GPUs (ranks wrap over the devices)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no HIP library: a trivial numpy stand-in for the hot path, to exercise the rank launcher, "
+                         "the process group and the JSON contract on CPU (tests/test_bench_launcher.py); never a measurement")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # dry-run fault injection for the launcher test
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N child ranks of this very script.
+
+    The parent never imports torch and never touches the GPU (a process that has initialised the GPU must not be
+    replaced or forked into ranks); children are ordinary subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    exactly what `python -m torch.distributed.run --nproc-per-node N` would give them.  Rank 0 inherits stdout and prints the
+    one JSON line.  The first non-zero exit ends the job: the other children are terminated (by PID) and the code is returned.
+    """
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = code
+    for p in live:  # a rank failed: the others would wait in a barrier for ever
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with code %d; job aborted\n" % rc)
+    return rc
+
+
+class DryEngine:
+    """--dry-run: stands where the asw context stands, computes a checksum on the CPU.  Exercises launcher, group, JSON."""
+
+    def __init__(self):
+        self.frames = {}
+        self.sums = {}
+
+    def upload_pair(self, i, L, R):
+        self.frames[i] = (L, R)
+
+    def match(self, i):
+        L, R = self.frames[i]
+        self.sums[i] = int(np.abs(L.astype(np.int32) - R.astype(np.int32)).sum())
+        return {"aggregate_ms": 0.0, "total_ms": 0.0, "aggregate_launches": 0}
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))  # parent: spawn the ranks, touch nothing else
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
-    ndev = torch.cuda.device_count()
-    device_index = local_rank % max(1, ndev)  # one process per GPU; wraps only when rehearsing N ranks on fewer GPUs
-    torch.cuda.set_device(device_index)
-    import aswstereomatch_amd as asw
-    from aswstereomatch_amd.dist import Group
-    from aswstereomatch_amd.synth import make_pair
-
-    group = Group(backend=args.backend, device=torch.device("cuda", device_index) if args.backend == "nccl" else None)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or drop the launcher and let "
+                         "--gpus N start the ranks)" % (args.gpus, world))
+    if args.dry_run and args.backend == "nccl":
+        args.backend = "gloo"
+    if args.fail_rank >= 0 and not args.dry_run:
+        raise SystemExit("--fail-rank is a --dry-run test hook")
 
     alg, ncand_fn, label = WORKLOADS[args.workload]
     W, H, D = args.width, args.height, args.disp
     ncand = ncand_fn(D)
-    ctx = asw.Context(device_index)
+
+    from aswstereomatch_amd.dist import Group
+    from aswstereomatch_amd.synth import make_pair
+
+    torch = None
+    device_index = -1
+    if args.dry_run:
+        group = Group(backend=args.backend)
+        eng = DryEngine()
+        ctx = None
+    else:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        ndev = torch.cuda.device_count()
+        if ndev < local_world and not args.oversubscribe:
+            raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible; one process per GPU "
+                             "(--oversubscribe only for rehearsals)" % (local_world, ndev))
+        device_index = local_rank % ndev if args.oversubscribe else local_rank
+        torch.cuda.set_device(device_index)
+        import aswstereomatch_amd as asw
+
+        group = Group(backend=args.backend, device=torch.device("cuda", device_index) if args.backend == "nccl" else None)
+        ctx = asw.Context(device_index)
+
+        class GpuEngine:
+            def upload_pair(self, i, L, R):
+                ctx.upload_pair(i, L, R)
+
+            def match(self, i):
+                ctx.match_resident(i, asw.DISPARITY_LEFT, alg, args.win, 0, D, keep_volume=True)
+                return ctx.timing()
+
+            def synchronize(self):
+                torch.cuda.synchronize()
+                ctx._lib.asw_synchronize(ctx._h)
+
+            def close(self):
+                ctx.close()
+
+        eng = GpuEngine()
+
+    if rank == args.fail_rank:
+        sys.stderr.write("bench.py: injected failure on rank %d\n" % rank)
+        os._exit(3)
 
     # synthetic frames of the named shape, resident in HBM before the timed region
     frames = []
     for i in range(args.frames):
         L, R, _ = make_pair(H, W, D, seed=1234 + rank * args.frames + i)
-        ctx.upload_pair(i, L, R)
-        if i == 0:
+        eng.upload_pair(i, L, R)
+        if rank == 0:
             frames.append((L, R))
 
     def barrier():
         group.barrier()
-        torch.cuda.synchronize()
-        ctx._lib.asw_synchronize(ctx._h)
+        eng.synchronize()
 
     def step():
         agg = 0.0
         tot = 0.0
         launches = 0
         for i in range(args.frames):
-            ctx.match_resident(i, asw.DISPARITY_LEFT, alg, args.win, 0, D, keep_volume=True)
-            t = ctx.timing()
+            t = eng.match(i)
             agg += t["aggregate_ms"]
             tot += t["total_ms"]
             launches += t["aggregate_launches"]
@@ -186,21 +317,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = group.max_over_ranks(elapsed)
+    pids = group.gather_ints(os.getpid())  # one entry per rank: the line shows how many processes really ran
 
     if rank == 0:
         frames_total = args.frames * args.steps * world
         value = W * H * frames_total / elapsed / 1e6
         n_frames_rank = args.frames * args.steps
-        agg_per_frame_ms = agg_ms / n_frames_rank          # dominant aggregation kernel(s), HIP events
-        balg = algorithmic_bytes(W, H, ncand)
-        achieved = balg / (agg_per_frame_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "disparity Mpix/s, %dx%d D=%d %s" % (W, H, D, label),
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -208,24 +330,71 @@ def main():
             "vs_baseline": None, "dtype": "f64" if alg in (2, 4) else "f32", "data": "synthetic",
             "config": {"workload": "%dx%d D=%d win=%d %s, %d frames/GPU/step resident in HBM, cost volume kept"
                                    % (W, H, D, args.win, args.workload, args.frames),
-                       "frames_per_gpu_per_step": args.frames, "candidates": ncand, "parallelism": "frames sharded, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "aggregate", "algorithmic_bytes_per_launch": balg,
-                         "avg_launch_ms": round(agg_per_frame_ms / max(1, launches / n_frames_rank), 4),
-                         "launches_per_frame": launches / n_frames_rank},
-            "kernel_ms_per_frame": {"aggregate": round(agg_per_frame_ms, 4), "all": round(tot_ms / n_frames_rank, 4)},
+                       "frames_per_gpu_per_step": args.frames, "candidates": ncand, "parallelism": "frames sharded, no collective",
+                       "ranks": world, "rank_pids": pids, "backend": args.backend if world > 1 else "none"},
         }
-        if alg == 2:
-            # this kernel is f64-VALU bound, not HBM bound: 1 f64 fma + 1 f64 add per (tap, d)
-            taps = W * H * ncand * (args.win * args.win - 1)
-            tf = taps * 3 / (agg_per_frame_ms * 1e-3) / 1e12  # fma = 2 flop, add = 1 flop, all f64
-            out["valu_roofline"] = {"bound": "f64 valu", "achieved": round(tf, 3), "peak": F64_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": round(tf / F64_PEAK_TFLOPS, 4),
-                                    "note": "3 f64 flop per (pixel,d,tap); cvt/f32 work not counted"}
+        if args.dry_run:
+            out["dry_run"] = True
+            out["data"] = "synthetic (dry run: CPU checksum stand-in, not a measurement)"
+            print(json.dumps(out), flush=True)
+        else:
+            agg_per_frame_ms = agg_ms / n_frames_rank          # dominant aggregation kernel(s), HIP events
+            balg = algorithmic_bytes(W, H, ncand)
+            achieved = balg / (agg_per_frame_ms * 1e-3) / 1e9
+            traffic = None
+            traffic_source = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+            if os.path.exists(pmc) and (W, H, D, args.win) == (1920, 1080, 128, 15):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    traffic_source = ("recorded: profiles/pmc_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "workload, FETCH_SIZE doubled per the gfx950 note); not re-measured in this run" % args.workload)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                               "kernel": "aggregate", "algorithmic_bytes_per_launch": balg,
+                               "avg_launch_ms": round(agg_per_frame_ms / max(1, launches / n_frames_rank), 4),
+                               "launches_per_frame": launches / n_frames_rank}
+            out["kernel_ms_per_frame"] = {"aggregate": round(agg_per_frame_ms, 4), "all": round(tot_ms / n_frames_rank, 4)}
+            if alg == 2:
+                # this kernel is f64-VALU bound, not HBM bound: 1 f64 fma + 1 f64 add per (tap, d)
+                taps = W * H * ncand * (args.win * args.win - 1)
+                tf = taps * 3 / (agg_per_frame_ms * 1e-3) / 1e12  # fma = 2 flop, add = 1 flop, all f64
+                out["valu_roofline"] = {"bound": "f64 valu", "achieved": round(tf, 3), "peak": F64_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": round(tf / F64_PEAK_TFLOPS, 4),
+                                        "note": "3 f64 flop per (pixel,d,tap); cvt/f32 work not counted"}
+
+    # ---- second leg, rank 0 only, after the timed region: the product's own multi-GPU API.  asw_stereo_match_batch shards
+    # --batch-frames frames (host buffers in and out) over ALL --gpus devices from ONE process; the other ranks are idle and
+    # wait on a CPU-side (gloo) barrier so that no RCCL kernel spins on the devices meanwhile.
+    if not args.dry_run and args.batch_frames > 0:
+        if rank == 0:
+            import aswstereomatch_amd as asw
+
+            devs = [k % torch.cuda.device_count() for k in range(world)] if args.oversubscribe else list(range(world))
+            want = [ctx.download_disparity(i, (H, W)) for i in range(len(frames))]  # resident-path results of this rank's frames
+            nb = args.batch_frames
+            outs = [np.full((H, W), -1.0, np.float32) for _ in range(nb)]  # touched once, as a frame loop reusing buffers has them
+            Lb = [frames[i % len(frames)][0] for i in range(nb)]
+            Rb = [frames[i % len(frames)][1] for i in range(nb)]
+            nw = min(nb, 2 * world)  # warm-up: creates the scheduler's contexts, scratch and pinned staging on every device
+            asw.stereoMatchingBatch(Lb[:nw], Rb[:nw], asw.DISPARITY_LEFT, alg, args.win, 0, D, device_ids=devs)
+            t1 = time.perf_counter()
+            asw.stereoMatchingBatch(Lb, Rb, asw.DISPARITY_LEFT, alg, args.win, 0, D, device_ids=devs, out=outs)
+            dt = time.perf_counter() - t1
+            same = all(np.array_equal(outs[i], want[i % len(frames)]) for i in range(nb))
+            out["batch_api"] = {"api": "asw_stereo_match_batch", "value": round(W * H * nb / dt / 1e6, 3), "unit": "Mpix/s",
+                                "frames": nb, "n_devices": world, "device_ids": devs, "ms_per_frame": round(dt / nb * 1e3, 3),
+                                "outputs_equal_resident_path": bool(same),
+                                "note": "one process, one host thread + context per device, pageable host buffers in and out "
+                                        "(PCIe-inclusive); never the headline value"}
+        group.cpu_barrier()
+
+    if rank == 0 and not args.dry_run:
         if world == 1:
-            # the same method through the host-buffer entry point (asw_stereo_match: H2D of both images, kernels,
-            # D2H of the disparity) -- the PCIe-inclusive rate; never the headline value
+            # the same method through the one-call host-buffer entry point (asw_stereo_match: H2D of both images, kernels,
+            # D2H of the disparity) -- the PCIe-inclusive rate of sequential calls; never the headline value
             L, R = frames[0]
             ctx.stereoMatching(L, R, asw.DISPARITY_LEFT, alg, args.win, 0, D)
             t1 = time.perf_counter()
@@ -235,28 +404,13 @@ def main():
             dt = (time.perf_counter() - t1) / nrep
             out["pcie_inclusive"] = {"value": round(W * H / dt / 1e6, 3), "unit": "Mpix/s", "ms_per_frame": round(dt * 1e3, 3),
                                      "note": "asw_stereo_match on pageable host buffers, no cost-volume download"}
-            # and through the batch scheduler (asw_stereo_match_batch: pinned staging, copies of frames n+1 / n-1 overlap
-            # the kernels of frame n); the warm-up call creates the scheduler's own context and scratch
-            nb = 4 * args.frames
-            outs = [np.zeros((H, W), np.float32) for _ in range(nb)]
-            for o in outs:
-                o.fill(-1.0)  # touched once, as a frame loop that reuses its buffers would have them
-            Lb = [frames[i % len(frames)][0] for i in range(nb)]
-            Rb = [frames[i % len(frames)][1] for i in range(nb)]
-            asw.stereoMatchingBatch(Lb[:2], Rb[:2], asw.DISPARITY_LEFT, alg, args.win, 0, D, device_ids=[device_index])
-            t1 = time.perf_counter()
-            asw.stereoMatchingBatch(Lb, Rb, asw.DISPARITY_LEFT, alg, args.win, 0, D, device_ids=[device_index], out=outs)
-            dt = (time.perf_counter() - t1) / nb
-            out["pcie_inclusive"]["batch"] = {"value": round(W * H / dt / 1e6, 3), "unit": "Mpix/s", "ms_per_frame": round(dt * 1e3, 3),
-                                              "note": "asw_stereo_match_batch, %d frames, host buffers in and out" % nb}
-        if not args.no_cpu and world == 1:
-            L, R = frames[0]
-            gpu_disp = ctx.download_disparity(0, (H, W))
-            cb = cpu_baseline(args, L, R, gpu_disp, alg)
-            if cb is not None:
-                out["cpu_baseline"] = cb
+            if not args.no_cpu:
+                gpu_disp = ctx.download_disparity(0, (H, W))  # slot 0 still holds frame 0's result of the timed loop
+                cb = cpu_baseline(args, L, R, gpu_disp, alg)
+                if cb is not None:
+                    out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    ctx.close()
+    eng.close()
     group.close()
 
 

@@ -14,6 +14,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -61,6 +62,13 @@ struct Mat {
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int channels() const { return channels_; }
     int depth() const { return depth_; }
+};
+
+// cv::Point where OpenCV is absent (key of getGeodesicDist's map, M.h:141)
+struct Point {
+    int x = 0, y = 0;
+    Point() {}
+    Point(int x_, int y_) : x(x_), y(y_) {}
 };
 
 namespace detail {
@@ -144,7 +152,7 @@ inline void stereoMatching(AswMat srcLeft, AswMat srcRight, AswMat& disparityMap
                            StereoMatchingAlgorithms algorithmType, int winSize = 15, int minDisparity = 0, int numDisparity = 64)
 {
     AswMat d = asw::detail::aggregate(srcLeft, srcRight, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_stereo_match(c, l, r, o, (int)disparityType, (int)algorithmType, winSize, minDisparity, numDisparity, nullptr);
+        return asw_stereo_match(c, l, r, o, (int)disparityType, (int)algorithmType, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "stereoMatching");
     disparityMap = d;  // `disparityMap = computeAdaptiveWeight...(...)`, M.cpp:58-82 (empty Mat on silent errors)
 }
@@ -219,7 +227,7 @@ inline AswMat computeAdaptiveWeight(AswMat leftImg, AswMat rightImg, double gamm
                                     int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_bilateral(c, l, r, o, gamma_c, gamma_g, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_bilateral(c, l, r, o, gamma_c, gamma_g, (int)dispType, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight");
 }
 
@@ -228,7 +236,7 @@ inline AswMat computeAdaptiveWeight_direct8(AswMat leftImg, AswMat rightImg, Dis
                                             int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_direct8(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_direct8(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_direct8");
 }
 
@@ -237,7 +245,7 @@ inline AswMat computeAdaptiveWeight_geodesic(AswMat leftImg, AswMat rightImg, Di
                                              int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_geodesic(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_geodesic(c, l, r, o, (int)dispType, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_geodesic");
 }
 
@@ -246,7 +254,7 @@ inline AswMat computeAdaptiveWeight_GuidedF_3(AswMat leftImg, AswMat rightImg, D
                                               int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_guided3(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_guided3(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_GuidedF_3");
 }
 
@@ -256,7 +264,7 @@ inline AswMat computeAdaptiveWeight_bilateralGrid(AswMat leftImg, AswMat rightIm
                                                   int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_bilgrid(c, l, r, o, (int)dispType, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_bilgrid(c, l, r, o, (int)dispType, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_bilateralGrid");
 }
 
@@ -265,7 +273,7 @@ inline AswMat computeAdaptiveWeight_BLO1(AswMat leftImg, AswMat rightImg, Dispar
                                          int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_blo1(c, l, r, o, (int)dispType, sampleRateR, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_blo1(c, l, r, o, (int)dispType, sampleRateR, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_BLO1");
 }
 
@@ -281,6 +289,63 @@ inline AswMat leftRightCheck(AswMat dispLeft, AswMat dispRight, float maxDiff = 
                           (float*)o.data, nInvalid);
     asw::detail::raise_unless_ok(rc, "leftRightCheck");
     return rc == ASW_OK ? out : AswMat();
+}
+
+// M.h:156 / M.cpp:2442-2503: ONE disparity; the view that is not the reference view arrives bordered by the caller
+// (copyMakeBorder by max_offset, M.cpp:2877-2878).  Empty Mat for an even window or a bordered view that is not wider.
+inline AswMat getCostSAD_d(AswMat leftImg, AswMat rightImg, int disparity, DisparityType dispType = DISPARITY_LEFT, int winSize = 35)
+{
+    if (leftImg.empty() || rightImg.empty()) return AswMat();
+    const AswMat& ref = dispType == DISPARITY_LEFT ? leftImg : rightImg;
+    AswMat cost = asw::detail::make(ref.rows, ref.cols, ASW_32F, 1);
+    asw_image li = asw::detail::view(leftImg), ri = asw::detail::view(rightImg), ci = asw::detail::view(cost);
+    if (ci.step != (size_t)ci.cols * 4) throw std::runtime_error("getCostSAD_d: continuous output expected");
+    int rc = asw_cost_sad_d(asw::detail::context(), &li, &ri, (float*)ci.data, disparity, (int)dispType, winSize);
+    asw::detail::raise_unless_ok(rc, "getCostSAD_d");
+    return rc == ASW_OK ? cost : AswMat();
+}
+
+// M.h:5-19: strict weak order of the map below (x first, then y)
+#ifndef ASW_REFERENCE_COMPARATORS_DEFINED
+#define ASW_REFERENCE_COMPARATORS_DEFINED
+#ifdef ASW_WITH_OPENCV
+typedef cv::Point AswPoint;
+#else
+typedef asw::Point AswPoint;
+#endif
+struct MY_COMP_Point2i {
+    bool operator()(const AswPoint& left, const AswPoint& right) const
+    {
+        if (left.x < right.x) return true;
+        if (left.x == right.x && left.y < right.y) return true;
+        return false;
+    }
+};
+#endif
+
+// M.h:141 / M.cpp:1392-1424: weightGeoDist[Point(x, y)] = winSize x winSize CV_32FC1 window of geodesic distances of pixel
+// (x, y); the map is cleared first; an even window returns without touching it (M.cpp:1394-1397).
+inline void getGeodesicDist(AswMat originImg, std::map<AswPoint, AswMat, MY_COMP_Point2i>& weightGeoDist, int winSize = 15,
+                            int iterTime = 3)
+{
+    if (winSize % 2 == 0 || originImg.empty()) return;
+    const int H = originImg.rows, W = originImg.cols;
+    const size_t cells = (size_t)winSize * winSize;
+    std::vector<float> dense((size_t)H * W * cells);  // [y][x][win][win], asw_geodesic_dist's layout
+    asw_image ii = asw::detail::view(originImg);
+    int rc = asw_geodesic_dist(asw::detail::context(), &ii, dense.data(), winSize, iterTime);
+    asw::detail::raise_unless_ok(rc, "getGeodesicDist");
+    if (rc != ASW_OK) return;
+    if (!weightGeoDist.empty()) weightGeoDist.clear();  // M.cpp:1406-1409
+    for (int x = 0; x < W; x++)                         // insertion order of the reference: x outer, y inner (M.cpp:1410-1412)
+        for (int y = 0; y < H; y++) {
+            AswMat w = asw::detail::make(winSize, winSize, ASW_32F, 1);
+            asw_image wi = asw::detail::view(w);
+            for (int r = 0; r < winSize; r++)
+                std::memcpy((uint8_t*)wi.data + (size_t)r * wi.step, dense.data() + ((size_t)y * W + x) * cells + (size_t)r * winSize,
+                            (size_t)winSize * 4);
+            weightGeoDist[AswPoint(x, y)] = w;
+        }
 }
 
 // M.h:165
@@ -301,7 +366,7 @@ inline AswMat computeAdaptiveWeight_GuidedF(AswMat leftImg, AswMat rightImg, Dis
                                             int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_guided(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_guided(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_GuidedF");
 }
 
@@ -310,7 +375,7 @@ inline AswMat computeAdaptiveWeight_GuidedF_2(AswMat leftImg, AswMat rightImg, D
                                               int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_guided2(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_guided2(c, l, r, o, (int)dispType, eps, winSize, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_GuidedF_2");
 }
 
@@ -320,6 +385,6 @@ inline AswMat computeAdaptiveWeight_WeightedMedian(AswMat leftImg, AswMat rightI
                                                    int minDisparity = 186, int numDisparity = 144)
 {
     return asw::detail::aggregate(leftImg, rightImg, [&](asw_ctx* c, asw_image* l, asw_image* r, asw_image* o) {
-        return asw_aggregate_wmedian(c, l, r, o, (int)dispType, winSize, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr);
+        return asw_aggregate_wmedian(c, l, r, o, (int)dispType, winSize, sampleRateS, sampleRateR, minDisparity, numDisparity, nullptr, 0);
     }, "computeAdaptiveWeight_WeightedMedian");
 }

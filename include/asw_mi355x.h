@@ -98,16 +98,24 @@ int asw_device_count(void);
  * selector's (gamma_c=30, gamma_g=20; eps=1e-6; rateS=rateR=10).
  * cost_volume_out (optional, may be NULL): aggregated cost volume, [n][rows][cols] f32 with
  * n = asw_volume_planes(algorithm, num_d): num_d, or num_d + 1 for ADAPTIVE_WEIGHT, 8DIRECT, GEODESIC and BILATERAL_GRID, whose
- * candidate range is inclusive (M.cpp:1021,1074; 1171; 1447,1467; 2256,2280). */
+ * candidate range is inclusive (M.cpp:1021,1074; 1171; 1447,1467; 2256,2280).
+ * cost_volume_floats: capacity of cost_volume_out in floats (ignored when it is NULL); a buffer shorter than
+ * n * rows * cols is refused with ASW_ERR_BAD_ARGUMENT before anything is computed or written.  The same pair of
+ * arguments ends every asw_aggregate_* entry point below.
+ * These host-buffer entry points work on a private frame of the context: they never disturb the resident slots of
+ * asw_upload_pair / asw_match_resident. */
 int asw_stereo_match(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                      int disparity_type, int algorithm, int win_size, int min_disparity, int num_disparity,
-                     float* cost_volume_out);
+                     float* cost_volume_out, size_t cost_volume_floats);
 
 /* Planes of the cost volume `algorithm` produces for num_disparity candidates (what cost_volume_out must hold);
  * 0 for an algorithm the library does not serve. */
 int asw_volume_planes(int algorithm, int num_disparity);
 
-/* ---- the same, split so that inputs can stay resident in HBM (bench / pipelines) ---- */
+/* ---- the same, split so that inputs can stay resident in HBM (bench / pipelines) ----
+ * Slots are caller-numbered (0..4095).  asw_upload_pair / asw_preprocess_pair replace a slot's pair and drop its previous
+ * disparity and volume; asw_download_* return ASW_ERR_NO_FRAME until asw_match_resident has succeeded on the CURRENT
+ * pair of the slot (a failed match drops the results too). */
 int asw_upload_pair(asw_ctx* ctx, int slot, const asw_image* left, const asw_image* right);
 int asw_match_resident(asw_ctx* ctx, int slot, int disparity_type, int algorithm, int win_size,
                        int min_disparity, int num_disparity, int keep_volume);
@@ -131,46 +139,46 @@ int asw_download_disparity_u8(asw_ctx* ctx, int slot, asw_image* disp_u8, int no
 /* computeAdaptiveWeight, M.h:133-134, M.cpp:1016-1156 */
 int asw_aggregate_bilateral(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                             double gamma_c, double gamma_g, int disparity_type, int win_size,
-                            int min_disparity, int num_disparity, float* cost_volume_out);
+                            int min_disparity, int num_disparity, float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_direct8, M.h:135-136, M.cpp:1167-1319: the classic scheme on row + column + main diagonal of the
  * window, gamma_c = 30, gamma_g = win*2/3 (integer division).  DISPARITY_LEFT only: the reference's RIGHT branch indexes
  * its weight vectors with a negative tap coordinate (M.cpp:1291-1295) -> ASW_ERR_UNSUPPORTED_LAYOUT. */
 int asw_aggregate_direct8(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, int win_size, int min_disparity, int num_disparity,
-                          float* cost_volume_out);
+                          float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_geodesic, M.h:142-143, M.cpp:1436-1534 */
 int asw_aggregate_geodesic(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                            int disparity_type, int win_size, int min_disparity, int num_disparity,
-                           float* cost_volume_out);
+                           float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_GuidedF, M.h:166-168, M.cpp:2867-2963 */
 int asw_aggregate_guided(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                          int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                         float* cost_volume_out);
+                         float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_GuidedF_2, M.h:169-171, M.cpp:2976-3050 */
 int asw_aggregate_guided2(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                          float* cost_volume_out);
+                          float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_GuidedF_3, M.h:172-174, M.cpp:3063-3137: normalised NCC planes (computeNCC, M.cpp:924-1013) filtered
  * with the 6-channel guide [L, R shifted by d] (LEFT) or with the plain right image (RIGHT, M.cpp:3110) */
 int asw_aggregate_guided3(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, double eps, int win_size, int min_disparity, int num_disparity,
-                          float* cost_volume_out);
+                          float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_BLO1, M.h:157-159, M.cpp:2505-2725 (min_disparity must be 0: the reference indexes its
  * per-key slices with the absolute offset) */
 int asw_aggregate_blo1(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                        int disparity_type, double sample_rate_r, int win_size, int min_disparity, int num_disparity,
-                       float* cost_volume_out);
+                       float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_bilateralGrid, M.h:155-157, M.cpp:2253-2430 (grid: createBilGrid M.cpp:1831-2185, enum 5 calls it with
  * rates 10, 10): offsets min_d .. min_d+num_d inclusive, cost volume num_d+1 planes (NaN / inf where the interpolated count is 0).
  * DISPARITY_LEFT only -- the reference's RIGHT branch reads one column past the row (M.cpp:1929, 2356).
  * sample_rate_r >= 2.55 (at most 101 bins per range axis). */
 int asw_aggregate_bilgrid(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, double sample_rate_s, double sample_rate_r, int min_disparity,
-                          int num_disparity, float* cost_volume_out);
+                          int num_disparity, float* cost_volume_out, size_t cost_volume_floats);
 /* computeAdaptiveWeight_WeightedMedian, M.h:179-182, M.cpp:3228-3383 */
 int asw_aggregate_wmedian(asw_ctx* ctx, const asw_image* left, const asw_image* right, asw_image* disp,
                           int disparity_type, int win_size, double rate_s, double rate_r, int min_disparity,
-                          int num_disparity, float* cost_volume_out);
+                          int num_disparity, float* cost_volume_out, size_t cost_volume_floats);
 
 /* ---- cost builders (M.h:101-113, 156) : outputs are dense d-major volumes ---- */
 /* computeAD, M.cpp:208-292: cost u8 [num_d][rows][cols]; 1- or 3-channel 8U input */
@@ -190,6 +198,15 @@ int asw_cost_similarity(asw_ctx* ctx, const asw_image* left, const asw_image* ri
 /* getCostSAD_d for every d as called from M.cpp:2884-2898: box mean of gray abs-diff */
 int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost,
                  int disparity_type, int win_size, int min_disparity, int num_disparity);
+
+/* getCostSAD_d itself, M.h:156, M.cpp:2442-2503: ONE disparity, and the image that is not the reference view arrives
+ * already bordered by the caller (wider by the caller's max_offset; M.cpp:2877-2878, 2884-2898): DISPARITY_LEFT reads
+ * right(Rect(right.cols - left.cols - disparity, 0, left.cols, rows)), DISPARITY_RIGHT reads left(Rect(disparity, 0,
+ * right.cols, rows)).  1- or 3-channel 8U inputs (3: BGR2GRAY first).  cost: f32 rows x cols of the reference view.
+ * ASW_ERR_SIZE_MISMATCH where the reference returns Mat() (bordered image not wider, M.cpp:2473-2476, 2488-2491),
+ * ASW_ERR_BAD_ARGUMENT for a ROI outside the bordered image (cv::Exception in the reference). */
+int asw_cost_sad_d(asw_ctx* ctx, const asw_image* left, const asw_image* right, float* cost, int disparity,
+                   int disparity_type, int win_size);
 
 /* computeNCC, volume overload, M.h:121-122, M.cpp:924-1013: cost = sum(l*r) / (sum(l*l)*sum(r*r)) on mean-removed windows of
  * the RGB2GRAY images; normalized != 0: every plane min-max normalised as the reference stores it, 0: the raw planes.

@@ -82,6 +82,19 @@ def test_shim_matches_ctypes_path(tmp_path):
         assert r.returncode == 0 and r.stdout.startswith("ok 40 72 planes=4 sd=3 same=%d" % (1 if alg == 5 else -1)), (r.stdout, r.stderr)
         got = np.fromfile(out, np.float32).reshape(40, 72)
         assert np.array_equal(got, ctx.stereoMatching(L, R, asw.DISPARITY_LEFT, alg, 7, 0, 10))
+    # the two header functions the round-1 shim lacked (M.h:141, 156): getGeodesicDist's std::map form and getCostSAD_d on a
+    # caller-bordered view
+    pre = tmp_path / "extra"
+    r = subprocess.run([EXE, "40", "72", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), "2", "7", "0", "10", str(tmp_path / "y.raw"), str(pre)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "geo=%d sadd=1" % (40 * 72) in r.stdout, (r.stdout, r.stderr)
+    sad = np.fromfile(str(pre) + ".sad", np.float32).reshape(40, 72)
+    assert np.array_equal(sad, ctx.getCostSAD(L, R, asw.DISPARITY_LEFT, 7, 0, 10)[1])
+    Rb = np.concatenate([R[:, :9][:, ::-1], R], axis=1)            # REFLECT border of max_offset = 9 columns on the left
+    assert np.array_equal(sad, ctx.getCostSAD_d(L, Rb, 1, asw.DISPARITY_LEFT, 7))
+    assert ctx.getCostSAD_d(L, R, 1, asw.DISPARITY_LEFT, 7) is None     # not bordered: Mat() in the reference
+    geo = np.fromfile(str(pre) + ".geo", np.float32).reshape(7, 7)
+    assert np.array_equal(geo, ctx.getGeodesicDist(L, 7, 3)[2, 3])
     # even window: the reference returns an empty Mat (M.cpp:1440-1443) -> so does the shim
     r = subprocess.run([EXE, "40", "72", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), "4", "6", "0", "10", str(tmp_path / "x.raw")],
                        capture_output=True, text=True, timeout=120)

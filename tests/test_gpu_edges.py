@@ -245,3 +245,76 @@ def test_six_channel_guided_filter_with_the_reference_default_window(ctx, oracle
     P = np.random.default_rng(win).random((40, 120), dtype=np.float32)
     guide = np.concatenate([L, R], axis=2)
     assert np.allclose(ctx.getGuidedFilter(guide, P, win, 1e-6), oracle.guided_filter(guide, P, win, 1e-6)[1], rtol=1e-4, atol=1e-30)
+
+
+# ---------------------------------------------------------------- resident slots: no stale results
+def test_downloads_never_return_another_frames_result(ctx, oracle):
+    """asw_upload_pair into a slot drops the slot's previous disparity and volume: before the fix a download right after
+    uploading a LARGER pair copied rows*cols*4 bytes out of the old, smaller allocation (out-of-bounds device read), and
+    with an equal size it silently returned the previous frame's map."""
+    small = make_pair(20, 40, 6, seed=1, block=8)[:2]
+    large = make_pair(60, 130, 6, seed=2, block=8)[:2]
+    same = make_pair(20, 40, 6, seed=3, block=8)[:2]
+    ctx.upload_pair(11, *small)
+    ctx.match_resident(11, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 6, keep_volume=True)
+    d_small = ctx.download_disparity(11, (20, 40))
+    assert ctx.download_volume(11, (7, 20, 40)).shape == (7, 20, 40)
+    for nxt, shape in ((large, (60, 130)), (same, (20, 40))):
+        ctx.upload_pair(11, *nxt)
+        for call in (lambda: ctx.download_disparity(11, shape), lambda: ctx.download_disparity_u8(11, shape),
+                     lambda: ctx.download_volume(11, (7,) + shape)):
+            with pytest.raises(asw.AswError) as e:
+                call()
+            assert e.value.status == asw.ERR_NO_FRAME
+        ctx.match_resident(11, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 6)
+        rc, want, _ = oracle.asw_classic(nxt[0], nxt[1], 30, 20, 0, 5, 0, 6)
+        assert rc == 0 and np.array_equal(ctx.download_disparity(11, shape), want)
+        with pytest.raises(asw.AswError):  # this match kept no volume: the older one must not come back
+            ctx.download_volume(11, (7,) + shape)
+    assert not np.array_equal(d_small, ctx.download_disparity(11, (20, 40)))
+    # a failed match (even window) leaves no result behind either, and the resident API raises instead of returning quietly
+    with pytest.raises(asw.AswError) as e:
+        ctx.match_resident(11, LEFT, A.ADAPTIVE_WEIGHT_GEODESIC, 6, 0, 6)
+    assert e.value.status == asw.ERR_EVEN_WINDOW
+    with pytest.raises(asw.AswError) as e:
+        ctx.download_disparity(11, (20, 40))
+    assert e.value.status == asw.ERR_NO_FRAME
+    # a rejected upload empties the slot: nothing of the previous pair can be matched by accident
+    with pytest.raises(asw.AswError) as e:
+        ctx.upload_pair(11, same[0], same[1][:, :30])
+    assert e.value.status == asw.ERR_SIZE_MISMATCH
+    with pytest.raises(asw.AswError) as e:
+        ctx.match_resident(11, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 6)
+    assert e.value.status == asw.ERR_NO_FRAME
+
+
+def test_host_buffer_entry_points_leave_resident_slots_alone(ctx, oracle):
+    """asw_stereo_match & co. work on a private frame: upload_pair(0, A); stereoMatching(B); match_resident(0) computes on A."""
+    A_pair = make_pair(24, 50, 6, seed=21, block=8)[:2]
+    B_pair = make_pair(31, 77, 6, seed=22, block=8)[:2]
+    ctx.upload_pair(0, *A_pair)
+    dB = ctx.stereoMatching(B_pair[0], B_pair[1], LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 6)
+    ctx.computeAdaptiveWeight_GuidedF_2(B_pair[0], B_pair[1], LEFT, 1e-6, 5, 0, 6)
+    ctx.match_resident(0, LEFT, A.ADAPTIVE_WEIGHT, 5, 0, 6)
+    dA = ctx.download_disparity(0, (24, 50))
+    assert np.array_equal(dA, oracle.asw_classic(A_pair[0], A_pair[1], 30, 20, 0, 5, 0, 6)[1])
+    assert np.array_equal(dB, oracle.asw_classic(B_pair[0], B_pair[1], 30, 20, 0, 5, 0, 6)[1])
+
+
+def test_short_cost_volume_buffer_is_refused(ctx):
+    """cost_volume_floats: the C caller states its capacity; one plane short (the inclusive-range trap) is ASW_ERR_BAD_ARGUMENT."""
+    import ctypes as C
+
+    from aswstereomatch_amd import _image
+
+    L, R = make_pair(12, 20, 4, seed=5, block=8)[:2]
+    li, la = _image(L)
+    ri, ra = _image(R)
+    disp = np.zeros((12, 20), np.float32)
+    di, _ = _image(disp, 5)
+    guard = np.full(5 * 12 * 20 + 64, 7.0, np.float32)      # ADAPTIVE_WEIGHT with numD = 4 writes 5 planes
+    pv = guard.ctypes.data_as(C.c_void_p)
+    rc = ctx._lib.asw_stereo_match(ctx._h, C.byref(li), C.byref(ri), C.byref(di), 0, 2, 5, 0, 4, pv, 4 * 12 * 20)
+    assert rc == asw.ERR_BAD_ARGUMENT and (guard == 7.0).all()
+    rc = ctx._lib.asw_stereo_match(ctx._h, C.byref(li), C.byref(ri), C.byref(di), 0, 2, 5, 0, 4, pv, 5 * 12 * 20)
+    assert rc == 0 and (guard[5 * 12 * 20:] == 7.0).all() and not (guard[:5 * 12 * 20] == 7.0).all()

@@ -440,7 +440,9 @@ def test_preprocess_then_match_then_u8(ctx, oracle):
         assert np.array_equal(ctx.download_disparity_u8(3, (72, 128), normalize=norm), oracle.disparity_to_u8(want, norm))
     with pytest.raises(asw.AswError):   # no frame in that slot
         ctx.download_disparity_u8(9, (72, 128))
-    assert ctx.preprocess_pair(3, L, R[:, :200], (128, 72)) is False and asw.last_status() == asw.ERR_SIZE_MISMATCH
+    with pytest.raises(asw.AswError) as e:   # the resident API has no reference behaviour to mimic: it raises
+        ctx.preprocess_pair(3, L, R[:, :200], (128, 72))
+    assert e.value.status == asw.ERR_SIZE_MISMATCH and asw.last_status() == asw.ERR_SIZE_MISMATCH
 
 
 # ---------------------------------------------------------------- bilateral grid (enum 5, inventory #12)
