@@ -103,6 +103,7 @@ extern "C" void asw_destroy(asw_ctx* ctx)
     for (auto& kv : ctx->scratch) kv.second.release();
     ctx->bil.taps.release();
     ctx->bil.lut.release();
+    ctx->bil.cells.release();
     ctx->wm_lut2.release();
     ctx->wm_wd.release();
     for (int i = 0; i < 4; i++)

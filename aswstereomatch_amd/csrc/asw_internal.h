@@ -53,6 +53,7 @@ struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
     int ntaps = 0, ncls = 0;
     DevBuf taps;  // int4 per tap
     DevBuf lut;   // float [ncls][256]
+    DevBuf cells; // kind 0, win 15, not mirrored: int4 per window cell (kx = -3..17, ky = 0..14) for k_asw_bilateral_xq
 };
 
 struct asw_ctx {
@@ -93,7 +94,14 @@ struct BilateralLaunch {
     double* partE;  // optional scratch [max_slices][H][W]: per-slice winners when the d range is split over grid.z
     float* partD;
     int max_slices;
+    int c_begin = 0;  // > 0: only candidates [c_begin, nD); the running minimum is resumed from partE / partD ([H][W])
 };
+// xq form of the classic kernel (k_bilateral_xq.hip): candidates [0, bilateral_xq_candidates()) of a DISPARITY_LEFT, win = 15
+// problem with nD >= bilateral_xq_min_candidates(); writes the running minimum to bestE / bestD for the tail launch
+int bilateral_xq_candidates();
+int bilateral_xq_min_candidates();
+int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
+                        const float* lut, float* vol, double* bestE, float* bestD);
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 // winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d
 int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp);

@@ -77,11 +77,27 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int kind, int win, double gamma
         taps[i].w = cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256;
     }
     for (int i = nt; i < nt_pad; i++) taps[i] = make_int4(0, 0, 0, zero_cls * 256);
+    // Cell-indexed form of the same table for k_asw_bilateral_xq: window cell (kx, ky) -> the weight map that is applied to the
+    // sample at that cell, {dx, dy of the direction the map was BUILT for, class * 256}.  Columns kx = -3..17 (units run up to
+    // three columns behind the step counter); the all-zero class stands for "no tap": outside the window and the one cell the
+    // reference's index arithmetic skips (kernel_x 7, kernel_y 8: M.cpp:1090-1099 jumps from i = 112 to the cell of i + 1).
+    std::vector<int4> cells;
+    if (kind == 0 && win == 15 && !mirror) {
+        cells.assign(21 * 15, make_int4(0, 0, zero_cls * 256, 0));
+        for (int i = 0; i < nt; i++) {
+            const int kx = dxs[i] + h, ky = dys[i] + h;
+            cells[(kx + 3) * 15 + ky] = make_int4(dxw[i], dyw[i], cls_of_r2[dxw[i] * dxw[i] + dyw[i] * dyw[i]] * 256, 1);
+        }
+    }
     ASW_TRY(t.taps.ensure((taps.size() > 4 ? taps.size() : 4) * sizeof(int4)));  // never a null table, even for win = 1 (no taps)
     ASW_TRY(t.lut.ensure(lut.size() * sizeof(float)));
     if (!taps.empty())  // win = 1 has no taps at all (every E is 0/0)
         ASW_HIP_TRY(hipMemcpyAsync(t.taps.p, taps.data(), taps.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     ASW_HIP_TRY(hipMemcpyAsync(t.lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!cells.empty()) {
+        ASW_TRY(t.cells.ensure(cells.size() * sizeof(int4)));
+        ASW_HIP_TRY(hipMemcpyAsync(t.cells.p, cells.data(), cells.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    }
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
     t.kind = kind; t.win = win; t.gamma_c = gamma_c; t.gamma_g = gamma_g; t.mirror = mirror; t.ntaps = nt_pad;
     t.ncls = (int)r2s.size() + 1;
@@ -127,6 +143,26 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     a.vol = keep_volume ? f->vol.as<float>() : nullptr;
     a.disp = f->disp.as<float>();
     a.partE = nullptr; a.partD = nullptr; a.max_slices = 0;
+    // Long candidate ranges of the reference's own configuration (DISPARITY_LEFT, 15x15) take the xq form of the kernel for the
+    // first 125 candidates and this kernel for the tail.  minD <= 48: the leftmost tile must still hold image columns 0..7 when
+    // positions clamp to column 0.  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B measurements, tests).
+    const char* xq_env = getenv("ASW_BILATERAL_XQ");
+    const bool use_xq = !direct8 && !flip && mp.win == 15 && nD >= bilateral_xq_min_candidates() && mp.minD <= 48 && W >= 64 &&
+                        !(xq_env && xq_env[0] == '0');
+    if (use_xq) {
+        DevBuf& pe = ctx->buf("bil_partE");
+        DevBuf& pd = ctx->buf("bil_partD");
+        ASW_TRY(pe.ensure((size_t)H * W * sizeof(double)));
+        ASW_TRY(pd.ensure((size_t)H * W * sizeof(float)));
+        a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = 1;
+        a.c_begin = bilateral_xq_candidates();
+        ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        ASW_TRY(launch_bilateral_xq(ctx->stream, a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol, a.partE, a.partD));
+        ASW_TRY(launch_bilateral(ctx->stream, a));
+        ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->timing.aggregate_launches = 2;
+        return ASW_OK;
+    }
     if ((size_t)H * W <= (size_t)1 << 20) {  // small frames only: scratch for the grid.z split of the disparity range
         const int max_slices = 8;
         DevBuf& pe = ctx->buf("bil_partE");

@@ -42,6 +42,8 @@ struct BilParams {
     int H, W, h, minD, nD, ntaps;
     int flip;  // 1: the problem is mirrored in x (DISPARITY_RIGHT = DISPARITY_LEFT on mirrored, swapped images)
     int cand_per_z;  // candidates per grid.z slice (multiple of 16); small images split the d range over grid.z
+    int c_begin;     // first candidate of this launch; > 0: the tail of a range whose head k_asw_bilateral_xq has done --
+                     // the running minimum is then resumed from partE / partD ([H][W], grid.z == 1)
 };
 
 constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -280,8 +282,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
     double bestE = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
     float bestD = 0.0f;
+    if (p.c_begin > 0) {  // resume the strict-'<' scan where the head launch stopped (ascending d is preserved)
+        const int xr = x0 + (tid & 63), yr = y0 + (tid >> 6);
+        if (xr < W && yr < H) {
+            const size_t o = (size_t)yr * W + (p.flip ? W - 1 - xr : xr);
+            bestE = partE[o];
+            bestD = partD[o];
+        }
+    }
     // this workgroup's candidate range [c0, cEnd): the whole range, or one grid.z slice of it for small images
-    int c0 = blockIdx.z * p.cand_per_z;
+    int c0 = p.c_begin + blockIdx.z * p.cand_per_z;
     const int cEnd = min(p.nD, c0 + p.cand_per_z);
     for (; c0 + 16 <= cEnd; c0 += 16) process_chunk<16, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD);
     if (cEnd - c0 >= 8) { process_chunk<8, G>(p, gR, taps, lut, vol, lay, smem, c0, bestE, bestD); c0 += 8; }
@@ -321,6 +331,8 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
 {
     BilParams p;
     p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps; p.flip = a.flip;
+    p.c_begin = a.c_begin;
+    if (a.c_begin < 0 || a.c_begin >= a.nD || (a.c_begin > 0 && !(a.partE && a.partD))) return ASW_ERR_BAD_ARGUMENT;
     const Layout lay(p.h, G);
     if (lay.total > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     auto kern = k_asw_bilateral<HH, G, WPE>;
@@ -330,9 +342,9 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
     if (a.ntaps % G != 0) return ASW_ERR_BAD_ARGUMENT;  // cannot happen for odd windows
     // Small images do not fill 256 CUs with tiles alone (C2: 450x375 -> 752 tiles): split the candidate range over
     // grid.z in multiples of 16 until there are ~2048 workgroups, and merge the per-slice winners afterwards.
-    const int tiles = grid.x * grid.y, chunks16 = (a.nD + 15) / 16;
+    const int tiles = grid.x * grid.y, chunks16 = (a.nD - a.c_begin + 15) / 16;
     int nz = 1;
-    if (a.partE && a.partD && tiles < 2048) nz = std::min(chunks16, std::min(a.max_slices, (2048 + tiles - 1) / tiles));
+    if (a.c_begin == 0 && a.partE && a.partD && tiles < 2048) nz = std::min(chunks16, std::min(a.max_slices, (2048 + tiles - 1) / tiles));
     const int chunks_per_z = (chunks16 + nz - 1) / nz;
     nz = (chunks16 + chunks_per_z - 1) / chunks_per_z;
     p.cand_per_z = chunks_per_z * 16;

@@ -1,0 +1,299 @@
+// Classic bilateral adaptive-support-weight aggregation (computeAdaptiveWeight, M.cpp:1016-1156), second kernel form:
+// thread = 4 pixels x 4 right-image positions ("xq blocking").  Used for DISPARITY_LEFT, 15x15 windows and long candidate
+// ranges (the reference's call site at 1080p, configs C5/C3-sized frames); everything else stays on k_asw_bilateral.
+//
+// Per (pixel x, candidate d) the reference adds, in tap order i (kernel_x = i / 15 outer, kernel_y = i % 15 inner):
+//     ab   = wL_i(y,x) * wR_i(y, max(0,x-d))          f32 product
+//     num += ab * |gL(ny,nx) - gR(ny, max(0,nx-d))|   f64        nx = clamp(x - 7 + kernel_x), ny = clamp(y - 7 + kernel_y)
+//     den += ab                                       f64
+// Put q = x - d (the right-image position of the pair).  Then
+//     * the weight pair of a unit is (wL_i(x), wR_i(q))                       -> outer product over a block of x's and q's
+//     * away from the right image border its cost sample is |gL(x+kx-7) - gR(q+kx-7)|: the SAME value that the unit
+//       (x+1, q+1) -- same d, next pixel -- needs one tap column earlier.
+// A thread owns pixels X..X+3 and positions Q..Q+3 (16 units, d = X+a - (Q+b)); unit (a,b) runs b tap columns behind the
+// thread's step counter K (kx = K - b), so all units on a diagonal a-b (one d, up to four pixels) consume ONE cost value per
+// step: 7 f64 subtractions per 16 units, and nothing is converted from bytes in the inner loop.  Every unit still adds its own
+// taps in ascending i, in f64, with the exact product -- E is bit-identical to the reference order (fma(ab,c,num) == num + ab*c
+// because ab*c is exact: 24-bit x 8-bit significands).
+//
+// Workgroup = one image row x 64 pixels x 32 position blocks (d = minD + 4j + a - b, j < 32): 8 wavefronts, lane -> (pixel
+// group g = lane & 15, position block 4*wave + (lane >> 4)).  All 512 threads share the staged weights of a step:
+//     left : wL(x, tap column kx)   for the 64 pixels        -> ring of 5 tap columns in LDS (a column is used for 4 steps)
+//     right: wR(q, tap column K-b)  for the 188 positions    -> b = (q - Q) mod 4 is a property of the position, so the buffer of
+//            step K holds, per position, exactly the tap column that position's units consume at step K (double buffered)
+// i.e. 7.4 weight evaluations per thread and step instead of 33 with wave-private staging, one workgroup barrier per step
+// (18 steps of 15 rows), no cost tile, gray tiles as f64 in LDS.  Candidates c = d - minD in [0, 125) are finished here (WTA
+// partial + volume); the tail [125, nD) is left to k_asw_bilateral, which resumes from this kernel's running minimum.
+#include <stdlib.h>
+
+#include "asw_internal.h"
+
+namespace {
+
+constexpr int HH = 7;                     // half window
+constexpr int KS = 2 * HH + 1;            // 15
+constexpr int PXW = 64;                   // pixels per workgroup
+constexpr int NWAVE = 8;
+constexpr int NJ = 4 * NWAVE;             // position blocks per workgroup
+constexpr int NPOS = PXW + 4 * (NJ - 1);  // 188 right-image positions a workgroup touches
+constexpr int LWC = PXW + 2 * HH;         // left tile columns  [x0 - 7, x0 + 70]
+constexpr int RWC = NPOS + 2 * HH;        // right tile columns [posmin - 7, posmax + 7]
+constexpr int NSTEP = KS + 3;             // 18 steps: unit row b runs b tap columns behind
+constexpr int RING = 5;                   // tap columns of left weights kept (4 in use + the one being staged)
+constexpr int NFIN = 4 * NJ - 3;          // 125 candidates are complete for all four pixels of a group
+constexpr int NCELLCOL = NSTEP + 3;       // cell-table columns kx = -3 .. 17
+
+// LDS layout (bytes)
+constexpr int OFF_LD = 0;                               // double [KS][LWC]   left gray
+constexpr int OFF_RD = OFF_LD + KS * LWC * 8;           // double [KS][RWC]   right gray
+constexpr int OFF_WL = OFF_RD + KS * RWC * 8;           // float  [RING][KS][PXW]
+constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;    // float  [2][KS][NPOS]
+constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;      // u8     [KS][LW8]
+constexpr int LW8 = 80, RW8 = 204;                      // u8 row strides (multiples of 4)
+constexpr int OFF_R8 = OFF_L8 + KS * LW8;
+constexpr int LDS_TOTAL = OFF_R8 + KS * RW8;            // 79 620 B: two workgroups per CU
+constexpr int OFF_E64 = 0;                              // epilogue: double [NFIN][PXW] = 64 000 B over the dead tiles
+constexpr int OFF_PART = NFIN * PXW * 8;                // epilogue: per-part WTA partials, {double E; float d}[NWAVE][PXW]
+static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
+static_assert(OFF_PART + NWAVE * PXW * 16 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
+static_assert(OFF_RD % 16 == 0 && OFF_WL % 16 == 0 && OFF_WR % 16 == 0 && (KS * NPOS * 4) % 16 == 0 && (NPOS * 4) % 16 == 0, "b128 alignment");
+
+struct XqParams {
+    int H, W, minD;
+};
+
+__device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned idx)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lut) + (idx << 2));
+}
+
+// Stage the weights step `Kn` consumes: left tap column Kn (ring slot Kn % RING) and the right buffer Kn & 1.
+// Wave w evaluates window rows ky = w and w + 8; cells[(kx + 3) * KS + ky] = {dxw, dyw, class * 256, -}: the direction the
+// reference BUILT weight map i for (transposed w.r.t. the sample it is applied to), all-zero class for the
+// skipped cell and for kx outside the window.
+__device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ cells, const float* __restrict__ lut,
+                                              unsigned char* smem, int wave, int lane, int ctrL, int pclamp_lo, int pclamp_hi)
+{
+    const uint8_t* sL8 = smem + OFF_L8;
+    const uint8_t* sR8 = smem + OFF_R8;
+    float* sWL = reinterpret_cast<float*>(smem + OFF_WL) + (Kn % RING) * (KS * PXW);
+    float* sWR = reinterpret_cast<float*>(smem + OFF_WR) + (Kn & 1) * (KS * NPOS);
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ky = wave + 8 * rr;
+        if (ky >= KS) break;  // wave-uniform
+        if (Kn < KS) {        // left column Kn exists
+            const int4 ci = cells[(Kn + 3) * KS + ky];  // uniform: scalar load
+            const int nb = sL8[(HH + ci.y) * LW8 + (lane + HH + ci.x)];
+            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctrL, ci.z);
+            sWL[ky * PXW + lane] = lut_at(lut, idx);
+        }
+#pragma unroll
+        for (int r3 = 0; r3 < 3; r3++) {
+            const int p = lane + 64 * r3;
+            if (p < NPOS) {
+                const int b = p & 3;  // posmin == Q (mod 4): the unit row a position belongs to is a property of the position
+                const int4 ci = cells[(Kn - b + 3) * KS + ky];
+                // the weight is evaluated AT max(0, x - d) (M.cpp:1105); its neighbour is clamped from there (tile columns are
+                // replicate-clamped, so adding the direction needs no further clamp)
+                const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
+                const int ctr = sR8[HH * RW8 + pc];
+                const int nb = sR8[(HH + ci.y) * RW8 + pc + ci.x];
+                const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctr, ci.z);
+                sWR[ky * NPOS + p] = lut_at(lut, idx);
+            }
+        }
+    }
+}
+
+// One step: window rows ky = 0..14 of tap column K - b for every active unit row b (BLO <= b <= BHI).
+//   EDGE = false: the workgroup's windows never clamp at the right image border: one right gray per step.
+//   EDGE = true : per-diagonal sample columns (lc = min(x + kx - 7, W-1), rc = lc - d), computed once per step.
+template <int K, bool EDGE>
+__device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int xabs, int dbase, int W, int x0,
+                                         int posmin, double (&num)[4][4], double (&den)[4][4])
+{
+    constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;  // kx = K - b <= 14
+    constexpr int BHI = K < 3 ? K : 3;                  // kx = K - b >= 0
+    constexpr int DLO = 0 - BHI, DHI = 3 - BLO;         // diagonals a - b in use
+    const double* sLd = reinterpret_cast<const double*>(smem + OFF_LD);
+    const double* sRd = reinterpret_cast<const double*>(smem + OFF_RD);
+    const float* sWL = reinterpret_cast<const float*>(smem + OFF_WL);
+    const float* sWR = reinterpret_cast<const float*>(smem + OFF_WR) + (K & 1) * (KS * NPOS);
+
+    int iL[7], iR[7];
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int dl = DLO; dl <= DHI; dl++) {
+            const int lc = min(xabs + dl + K - HH, W - 1);        // clamped sample column (left clamp: by the tile)
+            const int rc = lc - (dbase + dl);                     // max(0, .) by the tile
+            iL[dl + 3] = min(max(lc - (x0 - HH), 0), LWC - 1);
+            iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
+        }
+    }
+    const double* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
+    const double* pr = sRd + qrel + K;    // tile column of Q + K - 7
+    const float* pwl = sWL + 4 * g;
+    const float* pwr = sWR + qrel;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ky++) {
+        double c[7];
+        if constexpr (!EDGE) {
+            const double gr = pr[ky * RWC];
+#pragma unroll
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - gr;
+        } else {
+#pragma unroll
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
+        }
+        const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * NPOS);
+        const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
+#pragma unroll
+        for (int b = BLO; b <= BHI; b++) {
+            const float4 wl4 = *reinterpret_cast<const float4*>(pwl + (((K - b) % RING) * KS + ky) * PXW);
+            const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const float ab = wl[a] * wr[b];                                   // f32 product, M.cpp:1104-1105
+                const double abd = (double)ab;
+                num[a][b] = __builtin_fma(abd, __builtin_fabs(c[a - b + 3]), num[a][b]);  // exact product: == num + ab*|c|
+                den[a][b] = den[a][b] + abd;                                      // M.cpp:1107-1108
+            }
+        }
+    }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void run_all_steps(unsigned char* smem, const int4* __restrict__ cells, const float* __restrict__ lut,
+                                              int wave, int lane, int g, int qrel, int xabs, int dbase, int W, int x0, int posmin,
+                                              int ctrL, int pclamp_lo, int pclamp_hi, double (&num)[4][4], double (&den)[4][4])
+{
+#define ASW_XQ_STEP(K)                                                                                   \
+    if ((K) + 1 < NSTEP) stage_weights((K) + 1, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi); \
+    run_step<(K), EDGE>(smem, g, qrel, xabs, dbase, W, x0, posmin, num, den);                            \
+    __syncthreads();
+    ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
+    ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
+    ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
+#undef ASW_XQ_STEP
+}
+
+// grid (ceil(W / 64), H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W]; bestE / bestD: [H][W]
+// running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150), to be resumed by the tail launch.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
+    XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
+    const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    const int x0 = blockIdx.x * PXW, y = blockIdx.y;
+    const int posmin = x0 - p.minD - 4 * (NJ - 1);
+
+    // ---- gray tiles, replicate-clamped (M.cpp:1059-1060, 1101-1106), as bytes (weight staging) and as f64 (cost samples)
+    {
+        uint8_t* sL8 = smem + OFF_L8;
+        uint8_t* sR8 = smem + OFF_R8;
+        double* sLd = reinterpret_cast<double*>(smem + OFF_LD);
+        double* sRd = reinterpret_cast<double*>(smem + OFF_RD);
+        for (int i = tid; i < KS * LWC; i += 512) {
+            const int r = i / LWC, c = i - r * LWC;
+            const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(x0 - HH + c, 0), W - 1);
+            const int v = gL[(size_t)yy * W + xx];
+            sL8[r * LW8 + c] = (uint8_t)v;
+            sLd[r * LWC + c] = (double)v;
+        }
+        for (int i = tid; i < KS * RWC; i += 512) {
+            const int r = i / RWC, c = i - r * RWC;
+            const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(posmin - HH + c, 0), W - 1);
+            const int v = gR[(size_t)yy * W + xx];
+            sR8[r * RW8 + c] = (uint8_t)v;
+            sRd[r * RWC + c] = (double)v;
+        }
+    }
+    __syncthreads();
+
+    const int g = lane & 15, jl = 4 * wave + (lane >> 4);  // pixel group, position block
+    const int qrel = 4 * g + 4 * (NJ - 1 - jl);            // Q - posmin, Q = x0 + 4g - minD - 4 jl
+    const int xabs = x0 + 4 * g;                           // X
+    const int dbase = p.minD + 4 * jl;                     // d of the diagonal a == b
+    const int ctrL = smem[OFF_L8 + HH * LW8 + lane + HH];  // this lane's pixel as the centre of left weights it stages
+    // positions are clamped into the image before the weight is looked up: max(0, x - d) (and <= W-1 for the lanes of a
+    // partial tile, whose results are discarded)
+    const int pclamp_lo = min(max(0 - posmin, 0), NPOS - 1), pclamp_hi = min(max(W - 1 - posmin, 0), NPOS - 1);
+
+    double num[4][4], den[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { num[a][b] = 0.0; den[a][b] = 0.0; }
+
+    stage_weights(0, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
+    __syncthreads();
+    // windows of in-image pixels reach the right border when x0 + 63 + 7 > W - 1
+    if (x0 + PXW - 1 + HH <= W - 1)
+        run_all_steps<false>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
+    else
+        run_all_steps<true>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
+    // (the last step ended with a barrier: the tiles are dead)
+
+    // ---- E = num / den (M.cpp:1111) -> LDS [candidate][pixel]; rows >= NFIN are incomplete (their other pixels belong to
+    // position blocks beyond this launch) and are recomputed by the tail launch
+    double* sE = reinterpret_cast<double*>(smem + OFF_E64);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = 4 * jl + a - b;
+            if (c >= 0 && c < NFIN) sE[c * PXW + 4 * g + a] = num[a][b] / den[a][b];
+        }
+    __syncthreads();
+    // ---- WTA (strict '<' while d ascends) and volume: thread -> (pixel, 16 consecutive candidates)
+    const int px = lane, part = wave;
+    const int x = x0 + px;
+    double be = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
+    float bd = 0.0f;
+    if (x < W) {
+        const int c1 = min(16 * part + 16, NFIN);
+        for (int c = 16 * part; c < c1; c++) {
+            const double E = sE[c * PXW + px];
+            if (vol) vol[((size_t)c * H + y) * W + x] = (float)E;
+            if (E < be) { be = E; bd = (float)(p.minD + c); }
+        }
+    }
+    double* sPE = reinterpret_cast<double*>(smem + OFF_PART);
+    float* sPD = reinterpret_cast<float*>(smem + OFF_PART + NWAVE * PXW * 8);
+    sPE[part * PXW + px] = be;
+    sPD[part * PXW + px] = bd;
+    __syncthreads();
+    if (tid < PXW && x < W) {
+        double e = 1.7976931348623157e308;
+        float d = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NWAVE; q++) {
+            const double eq = sPE[q * PXW + tid];
+            if (eq < e) { e = eq; d = sPD[q * PXW + tid]; }
+        }
+        bestE[(size_t)y * W + x] = e;
+        bestD[(size_t)y * W + x] = d;
+    }
+}
+
+}  // namespace
+
+int bilateral_xq_candidates() { return NFIN; }
+int bilateral_xq_min_candidates() { return 4 * NJ; }  // every unit of the launch must be a real candidate: nD >= 128
+
+// cells: int4[21 * 15] (see stage_weights); lut: float[ncls][256] with an all-zero class.
+int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
+                        const float* lut, float* vol, double* bestE, float* bestD)
+{
+    XqParams p{H, W, minD};
+    auto kern = k_asw_bilateral_xq;
+    // per device (the batch scheduler drives several from one process): set on every launch, it is a table write
+    ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    dim3 grid((W + PXW - 1) / PXW, H);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS_TOTAL, s, p, gL, gR, cells, lut, vol, bestE, bestD);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}

@@ -50,23 +50,11 @@ def algorithmic_bytes(W, H, n_cand):
     return 2 * W * H * 3 + W * H * n_cand * 4 + W * H * 4
 
 
-def host_cores():
-    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
-
-
 def cpu_baseline(args, L, R, gpu_disp, alg):
     """The oracle (CPU restatement of the reference method) timed on this host on a bounded sample."""
     from oracle import asw_oracle as O
 
-    cores = min(host_cores(), O.max_threads())
+    cores = O.usable_cores()
     O.set_threads(cores)
     H, W = L.shape[:2]
     D, win = args.disp, args.win

@@ -63,6 +63,20 @@ def max_threads():
     return int(lib().orc_get_max_threads())
 
 
+def usable_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows every
+    core of its host but grants a share of them; OpenMP teams larger than the share spin against each other), capped by
+    what the OpenMP runtime offers."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, max_threads()))
+
+
 def set_box_mode(mode):
     lib().orc_set_box_mode(int(mode))
 

@@ -17,5 +17,5 @@ def oracle():
     from oracle import asw_oracle
 
     asw_oracle.build()
-    asw_oracle.set_threads(asw_oracle.max_threads())  # every core the box gives: whole-frame comparisons at 1080p need them
+    asw_oracle.set_threads(asw_oracle.usable_cores())  # every core the box GRANTS (cgroup quota): whole-frame comparisons at 1080p need them
     return asw_oracle
