@@ -107,6 +107,12 @@ class Context:
         except Exception:
             pass
 
+    def set_gray_bits(self, bits):
+        """cvtColor(BGR2GRAY) constant set: 14 (OpenCV 4.1.0, default) or 15 (later 4.x) -- asw_set_gray_bits."""
+        rc = self._lib.asw_set_gray_bits(self._h, int(bits))
+        if rc != 0:
+            raise AswError(rc, "asw_set_gray_bits")
+
     # ---- helpers ----
     def _finish(self, rc, where):
         _state.status = rc

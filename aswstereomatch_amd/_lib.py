@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libasw_mi355x.so")
 
 # every symbol include/asw_mi355x.h declares
 ABI_SYMBOLS = [
-    "asw_create", "asw_destroy", "asw_status_string", "asw_device_count",
+    "asw_create", "asw_destroy", "asw_status_string", "asw_device_count", "asw_set_gray_bits",
     "asw_stereo_match", "asw_upload_pair", "asw_match_resident", "asw_download_disparity",
     "asw_download_volume", "asw_synchronize", "asw_get_timing",
     "asw_aggregate_bilateral", "asw_aggregate_geodesic", "asw_aggregate_guided", "asw_aggregate_guided2",
@@ -72,6 +72,7 @@ def lib():
         l.asw_download_disparity.argtypes = [P, I, IMG]
         l.asw_download_volume.argtypes = [P, I, P, C.c_size_t]
         l.asw_synchronize.argtypes = [P]
+        l.asw_set_gray_bits.argtypes = [P, I]
         l.asw_get_timing.argtypes = [P, C.POINTER(AswTiming)]
         l.asw_aggregate_bilateral.argtypes = [P, IMG, IMG, IMG, D, D, I, I, I, I, P, C.c_size_t]
         l.asw_aggregate_geodesic.argtypes = [P, IMG, IMG, IMG, I, I, I, I, P, C.c_size_t]

@@ -139,7 +139,7 @@ extern "C" int asw_bgr2gray(asw_ctx* ctx, const asw_image* bgr, uint8_t* gray)
     ASW_TRY(upload_image(ctx, bgr, d));
     size_t n = (size_t)bgr->rows * bgr->cols;
     ASW_TRY(g.ensure(n));
-    ASW_TRY(launch_bgr2gray(ctx->stream, d.as<uint8_t>(), bgr->rows, bgr->cols, g.as<uint8_t>()));
+    ASW_TRY(launch_bgr2gray(ctx->stream, d.as<uint8_t>(), bgr->rows, bgr->cols, g.as<uint8_t>(), ctx->gray_bits));
     ASW_HIP_TRY(hipMemcpyAsync(gray, g.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
@@ -261,8 +261,8 @@ extern "C" int asw_cost_sad(asw_ctx* ctx, const asw_image* left, const asw_image
     if (left->channels == 3) {  // M.cpp:2446-2456
         ASW_TRY(gl.ensure((size_t)H * W));
         ASW_TRY(gr.ensure((size_t)H * W));
-        ASW_TRY(launch_bgr2gray(ctx->stream, pl, H, W, gl.as<uint8_t>()));
-        ASW_TRY(launch_bgr2gray(ctx->stream, pr, H, W, gr.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pl, H, W, gl.as<uint8_t>(), ctx->gray_bits));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pr, H, W, gr.as<uint8_t>(), ctx->gray_bits));
         pl = gl.as<uint8_t>(); pr = gr.as<uint8_t>();
     }
     ASW_TRY(launch_cost_sad(ctx->stream, pl, pr, H, W, disparity_type, win_size, min_disparity, n, raw.as<float>()));
@@ -306,11 +306,11 @@ extern "C" int asw_cost_sad_d(asw_ctx* ctx, const asw_image* left, const asw_ima
     const uint8_t* pref = dref.as<uint8_t>();
     const uint8_t* pbord = dbord.as<uint8_t>();
     if (ref->channels == 3) {  // M.cpp:2446-2456
-        ASW_TRY(launch_bgr2gray(ctx->stream, pref, H, W, gref.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pref, H, W, gref.as<uint8_t>(), ctx->gray_bits));
         pref = gref.as<uint8_t>();
     }
     if (bord->channels == 3) {
-        ASW_TRY(launch_bgr2gray(ctx->stream, pbord, H, Wb, gbord.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, pbord, H, Wb, gbord.as<uint8_t>(), ctx->gray_bits));
         pbord = gbord.as<uint8_t>();
     }
     // the ROI of the bordered view as a dense plane; then |ref - roi| -> f32 -> boxFilter mean is launch_cost_sad at offset 0

@@ -120,6 +120,14 @@ extern "C" int asw_synchronize(asw_ctx* ctx)
     return ASW_OK;
 }
 
+// cvtColor(COLOR_BGR2GRAY / RGB2GRAY) constant set of every method that converts to gray (M.cpp:1031-1033, 2448-2454, 835-840)
+extern "C" int asw_set_gray_bits(asw_ctx* ctx, int bits)
+{
+    if (!ctx || (bits != 14 && bits != 15)) return ASW_ERR_BAD_ARGUMENT;
+    ctx->gray_bits = bits;
+    return ASW_OK;
+}
+
 extern "C" int asw_get_timing(asw_ctx* ctx, asw_timing* out)
 {
     if (!ctx || !out) return ASW_ERR_BAD_ARGUMENT;

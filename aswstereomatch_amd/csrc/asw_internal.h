@@ -59,6 +59,7 @@ struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
 struct asw_ctx {
     int device = 0;
     int prep_ntaps = 0;  // taps of the pre-processing bilateral filter (tables in buf("prep_tables"))
+    int gray_bits = 14;  // cvtColor(BGR2GRAY) constant set (asw_set_gray_bits): 14 = OpenCV 4.1.0, 15 = later 4.x
     hipStream_t stream = nullptr;
     std::vector<Frame> frames;  // resident slots of asw_upload_pair / asw_match_resident (caller-numbered)
     Frame host_frame;           // private frame of the host-buffer entry points (asw_stereo_match, asw_aggregate_*): never a slot
@@ -74,9 +75,10 @@ struct asw_ctx {
 };
 
 // ---- kernel launchers (each returns an asw_status; all work is enqueued on `s`) ----
-int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray);
+// bits: fixed-point width of the BT.601 constants, 14 (OpenCV 4.1.0, the reference's pin) or 15 (later 4.x): SURVEY App. A-1
+int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray, int bits);
 // cvtColor(COLOR_RGB2GRAY) applied to BGR data, as computeNCC does (M.cpp:835,840): the R and B coefficients swap
-int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray);
+int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray, int bits);
 int launch_cost_ad(hipStream_t s, const uint8_t* L, const uint8_t* R, int H, int W, int C, int disp_type, int minD,
                    int numD, int do_thresh /* 0: AD, 1: TAD mask, 2: SD */, int threshold, uint8_t* cost);
 int launch_wta(hipStream_t s, const float* vol, int n, int H, int W, int minD, float* disp);

@@ -132,8 +132,8 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
         ASW_TRY(f->vol.ensure((size_t)nD * H * W * 4));
         f->vol_floats = (size_t)nD * H * W;
     }
-    ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
-    ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
+    ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>(), ctx->gray_bits));
+    ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>(), ctx->gray_bits));
     BilateralLaunch a;
     a.gL = flip ? gr.as<uint8_t>() : gl.as<uint8_t>();  // RIGHT: reference image = right, read mirrored in the kernel
     a.gR = flip ? gl.as<uint8_t>() : gr.as<uint8_t>();
@@ -222,8 +222,8 @@ int run_ncc_cost(asw_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int H, int 
     ASW_TRY(s0.ensure(plane * 8)); ASW_TRY(s1.ensure(pplane * 8));
     // COLOR_RGB2GRAY on BGR data (M.cpp:835,840); reference image = left (LEFT) or right (RIGHT)
     if (channels == 3) {
-        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dR : dL, H, W, g0.as<uint8_t>()));
-        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dL : dR, H, W, g1.as<uint8_t>()));
+        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dR : dL, H, W, g0.as<uint8_t>(), ctx->gray_bits));
+        ASW_TRY(launch_rgb2gray(ctx->stream, right ? dL : dR, H, W, g1.as<uint8_t>(), ctx->gray_bits));
     } else {  // single-channel input is used as it is (M.cpp:833-841: cvtColor only for 3 channels)
         ASW_HIP_TRY(hipMemcpyAsync(g0.p, right ? dR : dL, plane, hipMemcpyDeviceToDevice, ctx->stream));
         ASW_HIP_TRY(hipMemcpyAsync(g1.p, right ? dL : dR, plane, hipMemcpyDeviceToDevice, ctx->stream));
@@ -346,8 +346,8 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
         ASW_TRY(gl.ensure(plane));
         ASW_TRY(gr.ensure(plane));
         ASW_TRY(colmm.ensure((size_t)2 * W * sizeof(int)));
-        ASW_TRY(launch_bgr2gray(ctx->stream, dL, H, W, gl.as<uint8_t>()));
-        ASW_TRY(launch_bgr2gray(ctx->stream, dR, H, W, gr.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, dL, H, W, gl.as<uint8_t>(), ctx->gray_bits));
+        ASW_TRY(launch_bgr2gray(ctx->stream, dR, H, W, gr.as<uint8_t>(), ctx->gray_bits));
         ASW_TRY(launch_cost_sad(ctx->stream, gl.as<uint8_t>(), gr.as<uint8_t>(), H, W, mp.disparity_type, mp.win, mp.minD, n,
                                 raw.as<float>()));  // M.cpp:2884-2889
         ASW_TRY(launch_guide_scales_lr(ctx->stream, right ? dR : dL, right ? dL : dR, H, W, mp.minD, n, mp.disparity_type,
@@ -522,8 +522,8 @@ static int run_blo1(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_vol
         f->vol_floats = plane * n;
     }
     if (f->channels == 3) {  // M.cpp:2514-2521
-        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
-        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>(), ctx->gray_bits));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>(), ctx->gray_bits));
     } else {
         ASW_HIP_TRY(hipMemcpyAsync(gl.p, f->L.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
         ASW_HIP_TRY(hipMemcpyAsync(gr.p, f->R.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
@@ -567,8 +567,8 @@ static int run_bilgrid(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
         f->vol_floats = plane * n;
     }
     if (f->channels == 3) {  // M.cpp:2271-2278
-        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>()));
-        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>()));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->L.as<uint8_t>(), H, W, gl.as<uint8_t>(), ctx->gray_bits));
+        ASW_TRY(launch_bgr2gray(ctx->stream, f->R.as<uint8_t>(), H, W, gr.as<uint8_t>(), ctx->gray_bits));
     } else {
         ASW_HIP_TRY(hipMemcpyAsync(gl.p, f->L.p, plane, hipMemcpyDeviceToDevice, ctx->stream));
         ASW_HIP_TRY(hipMemcpyAsync(gr.p, f->R.p, plane, hipMemcpyDeviceToDevice, ctx->stream));

@@ -5,9 +5,12 @@
 namespace {
 
 
-// cvtColor(COLOR_BGR2GRAY) 8U, OpenCV 4.1.0 14-bit fixed point (M.cpp:1031-1033; App. A-1)
-__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray, uint32_t k0, uint32_t k2)
+// cvtColor(COLOR_BGR2GRAY) 8U, fixed point (M.cpp:1031-1033; App. A-1): gray = (c0*k0 + c1*k1 + c2*k2 + half) >> shift.
+// OpenCV 4.1.0 (the reference's pin): 14 bits {1868, 9617, 4899}; later 4.x releases: 15 bits {3735, 19235, 9798}.
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray, uint32_t k0, uint32_t k1,
+                           uint32_t k2, uint32_t shift)
 {
+    const uint32_t half = 1u << (shift - 1);
     // 4 pixels per thread: 12 input bytes (3 dwords), 1 output dword
     int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -20,14 +23,14 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __re
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t g = (b[3 * k] * k0 + b[3 * k + 1] * 9617u + b[3 * k + 2] * k2 + 8192u) >> 14;
+            uint32_t g = (b[3 * k] * k0 + b[3 * k + 1] * k1 + b[3 * k + 2] * k2 + half) >> shift;
             out |= g << (8 * k);
         }
         *reinterpret_cast<uint32_t*>(gray + i) = out;
     } else {
         for (; i < n; i++) {
             const uint8_t* q = bgr + (size_t)i * 3;
-            gray[i] = (uint8_t)((q[0] * k0 + q[1] * 9617u + q[2] * k2 + 8192u) >> 14);
+            gray[i] = (uint8_t)((q[0] * k0 + q[1] * k1 + q[2] * k2 + half) >> shift);
         }
     }
 }
@@ -136,20 +139,26 @@ __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, int 
 
 }  // namespace
 
-int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray)
+int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray, int bits)
 {
     int n = H * W;
     int threads = 256, blocks = (n / 4 + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 1868u, 4899u);
+    if (bits == 15)
+        hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 3735u, 19235u, 9798u, 15u);
+    else
+        hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 1868u, 9617u, 4899u, 14u);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
 
-int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray)
+int launch_rgb2gray(hipStream_t s, const uint8_t* bgr, int H, int W, uint8_t* gray, int bits)
 {
     int n = H * W;
     int threads = 256, blocks = (n / 4 + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 4899u, 1868u);
+    if (bits == 15)
+        hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 9798u, 19235u, 3735u, 15u);
+    else
+        hipLaunchKernelGGL(k_bgr2gray, dim3(blocks), dim3(threads), 0, s, bgr, n, gray, 4899u, 9617u, 1868u, 14u);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

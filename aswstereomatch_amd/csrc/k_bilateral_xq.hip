@@ -51,7 +51,8 @@ constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;    // float  [2][KS][NPOS]
 constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;      // u8     [KS][LW8]
 constexpr int LW8 = 80, RW8 = 204;                      // u8 row strides (multiples of 4)
 constexpr int OFF_R8 = OFF_L8 + KS * LW8;
-constexpr int LDS_TOTAL = OFF_R8 + KS * RW8;            // 79 620 B: two workgroups per CU
+constexpr int OFF_CELL = OFF_R8 + KS * RW8;             // u32 [NCELLCOL * KS]: packed cell table (variant bit 1)
+constexpr int LDS_TOTAL = OFF_CELL + NCELLCOL * KS * 4; // 80 880 B: two workgroups per CU
 constexpr int OFF_E64 = 0;                              // epilogue: double [NFIN][PXW] = 64 000 B over the dead tiles
 constexpr int OFF_PART = NFIN * PXW * 8;                // epilogue: per-part WTA partials, {double E; float d}[NWAVE][PXW]
 static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
@@ -71,6 +72,20 @@ __device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned 
 // Wave w evaluates window rows ky = w and w + 8; cells[(kx + 3) * KS + ky] = {dxw, dyw, class * 256, -}: the direction the
 // reference BUILT weight map i for (transposed w.r.t. the sample it is applied to), all-zero class for the
 // skipped cell and for kx outside the window.
+// VAR bit 1: the cell table is read from LDS, packed as (dxw + 8) | (dyw + 8) << 4 | class << 8 (one LDS round trip instead of
+// a global one in front of the LUT gather).
+template <int VAR>
+__device__ __forceinline__ int4 cell_at(const int4* __restrict__ cells, const unsigned char* smem, int idx)
+{
+    if constexpr ((VAR & 2) != 0) {
+        const uint32_t u = reinterpret_cast<const uint32_t*>(smem + OFF_CELL)[idx];
+        return make_int4((int)(u & 15u) - 8, (int)((u >> 4) & 15u) - 8, (int)(u >> 8) << 8, 0);
+    } else {
+        return cells[idx];
+    }
+}
+
+template <int VAR>
 __device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ cells, const float* __restrict__ lut,
                                               unsigned char* smem, int wave, int lane, int ctrL, int pclamp_lo, int pclamp_hi)
 {
@@ -83,7 +98,7 @@ __device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ c
         const int ky = wave + 8 * rr;
         if (ky >= KS) break;  // wave-uniform
         if (Kn < KS) {        // left column Kn exists
-            const int4 ci = cells[(Kn + 3) * KS + ky];  // uniform: scalar load
+            const int4 ci = cell_at<VAR>(cells, smem, (Kn + 3) * KS + ky);  // uniform index
             const int nb = sL8[(HH + ci.y) * LW8 + (lane + HH + ci.x)];
             const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctrL, ci.z);
             sWL[ky * PXW + lane] = lut_at(lut, idx);
@@ -93,7 +108,7 @@ __device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ c
             const int p = lane + 64 * r3;
             if (p < NPOS) {
                 const int b = p & 3;  // posmin == Q (mod 4): the unit row a position belongs to is a property of the position
-                const int4 ci = cells[(Kn - b + 3) * KS + ky];
+                const int4 ci = cell_at<VAR>(cells, smem, (Kn - b + 3) * KS + ky);
                 // the weight is evaluated AT max(0, x - d) (M.cpp:1105); its neighbour is clamped from there (tile columns are
                 // replicate-clamped, so adding the direction needs no further clamp)
                 const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
@@ -163,13 +178,13 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     }
 }
 
-template <bool EDGE>
+template <bool EDGE, int VAR>
 __device__ __forceinline__ void run_all_steps(unsigned char* smem, const int4* __restrict__ cells, const float* __restrict__ lut,
                                               int wave, int lane, int g, int qrel, int xabs, int dbase, int W, int x0, int posmin,
                                               int ctrL, int pclamp_lo, int pclamp_hi, double (&num)[4][4], double (&den)[4][4])
 {
 #define ASW_XQ_STEP(K)                                                                                   \
-    if ((K) + 1 < NSTEP) stage_weights((K) + 1, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi); \
+    if ((K) + 1 < NSTEP) stage_weights<VAR>((K) + 1, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi); \
     run_step<(K), EDGE>(smem, g, qrel, xabs, dbase, W, x0, posmin, num, den);                            \
     __syncthreads();
     ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
@@ -180,6 +195,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const int4* _
 
 // grid (ceil(W / 64), H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W]; bestE / bestD: [H][W]
 // running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150), to be resumed by the tail launch.
+template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD)
@@ -210,10 +226,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             sR8[r * RW8 + c] = (uint8_t)v;
             sRd[r * RWC + c] = (double)v;
         }
+        if constexpr ((VAR & 2) != 0) {
+            uint32_t* sCell = reinterpret_cast<uint32_t*>(smem + OFF_CELL);
+            for (int i = tid; i < NCELLCOL * KS; i += 512) {
+                const int4 ci = cells[i];
+                sCell[i] = (uint32_t)(ci.x + 8) | ((uint32_t)(ci.y + 8) << 4) | ((uint32_t)(ci.z >> 8) << 8);
+            }
+        }
     }
     __syncthreads();
 
-    const int g = lane & 15, jl = 4 * wave + (lane >> 4);  // pixel group, position block
+    // lane -> (pixel group g, position block jl).  VAR bit 0: g's low three bits from the lane's low three bits and its bit 3
+    // from lane bit 5, so that the sixteen lanes one ds_read_b128 services together hold eight distinct g's (the f64 gray
+    // reads are 32 B apart per g: g and g + 8 share a bank)
+    const int g = (VAR & 1) ? ((lane & 7) | ((lane >> 2) & 8)) : (lane & 15);
+    const int jl = 4 * wave + ((VAR & 1) ? ((lane >> 3) & 3) : (lane >> 4));
     const int qrel = 4 * g + 4 * (NJ - 1 - jl);            // Q - posmin, Q = x0 + 4g - minD - 4 jl
     const int xabs = x0 + 4 * g;                           // X
     const int dbase = p.minD + 4 * jl;                     // d of the diagonal a == b
@@ -228,13 +255,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int b = 0; b < 4; b++) { num[a][b] = 0.0; den[a][b] = 0.0; }
 
-    stage_weights(0, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
+    stage_weights<VAR>(0, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
     __syncthreads();
     // windows of in-image pixels reach the right border when x0 + 63 + 7 > W - 1
     if (x0 + PXW - 1 + HH <= W - 1)
-        run_all_steps<false>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
+        run_all_steps<false, VAR>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
     else
-        run_all_steps<true>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
+        run_all_steps<true, VAR>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
     // (the last step ended with a barrier: the tiles are dead)
 
     // ---- E = num / den (M.cpp:1111) -> LDS [candidate][pixel]; rows >= NFIN are incomplete (their other pixels belong to
@@ -289,7 +316,9 @@ int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int
                         const float* lut, float* vol, double* bestE, float* bestD)
 {
     XqParams p{H, W, minD};
-    auto kern = k_asw_bilateral_xq;
+    int var = 3;
+    if (const char* e = getenv("ASW_XQ_VARIANT")) var = atoi(e) & 3;  // measurement hook: bit 0 lane map, bit 1 cell table in LDS
+    auto kern = var == 0 ? k_asw_bilateral_xq<0> : var == 1 ? k_asw_bilateral_xq<1> : var == 2 ? k_asw_bilateral_xq<2> : k_asw_bilateral_xq<3>;
     // per device (the batch scheduler drives several from one process): set on every launch, it is a table write
     ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     dim3 grid((W + PXW - 1) / PXW, H);

@@ -91,6 +91,12 @@ int asw_create(int device_id, asw_ctx** out);
 void asw_destroy(asw_ctx* ctx);
 const char* asw_status_string(int status);
 int asw_device_count(void);
+/* cvtColor(COLOR_BGR2GRAY) on 8U is fixed-point in OpenCV and its constants changed between releases: 14 bits
+ * {B 1868, G 9617, R 4899} in 4.1.0 -- the version the reference pins (aswStereoMatch.vcxproj:67,71), the default here --
+ * and 15 bits {3735, 19235, 9798} in later 4.x releases; the two differ by +-1 on a few percent of the pixels.  A maintainer
+ * who links the reference against a newer OpenCV selects 15 to keep bit-identical gray planes (classic, direct8, SAD, BLO1,
+ * bilateral grid, NCC all start from them; M.cpp:1031-1033, 2448-2454, 835-840).  bits: 14 or 15. */
+int asw_set_gray_bits(asw_ctx* ctx, int bits);
 
 /* ---- whole-method entry point: stereoMatching(), M.h:91-92, M.cpp:46-88 ----
  * disp: ASW_32F, 1 channel, rows x cols, caller-allocated; receives ABSOLUTE disparity

@@ -88,11 +88,15 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-/* cvtColor(COLOR_BGR2GRAY) on 8U: 14-bit fixed point BT.601, OpenCV 4.1.0 (A-1).
- * M.cpp:1031,1033,2448,2454. */
+/* cvtColor(COLOR_BGR2GRAY) on 8U: fixed-point BT.601 (A-1).  M.cpp:1031,1033,2448,2454.
+ * OpenCV 4.1.0 (the reference's pin) is believed to use the 14-bit constants; later 4.x releases use the 15-bit set.  The
+ * choice cannot be verified offline, so it is ONE switch here (and one in the library, asw_set_gray_bits): 14 by default. */
+static int g_gray_bits = 14;
+void orc_set_gray_bits(int bits) { g_gray_bits = (bits == 15) ? 15 : 14; }
 void orc_bgr2gray(const uint8_t* bgr, int H, int W, uint8_t* gray)
 {
-    const int B2Y = 1868, G2Y = 9617, R2Y = 4899, shift = 14;
+    const int wide = g_gray_bits == 15;
+    const int B2Y = wide ? 3735 : 1868, G2Y = wide ? 19235 : 9617, R2Y = wide ? 9798 : 4899, shift = wide ? 15 : 14;
     for (long i = 0; i < (long)H * W; i++) {
         int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
         gray[i] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (shift - 1))) >> shift);
@@ -876,7 +880,8 @@ int orc_asw_guided(const uint8_t* L, const uint8_t* R, int H, int W, int disp_ty
  * ------------------------------------------------------------------------------------- */
 void orc_rgb2gray(const uint8_t* bgr, int H, int W, uint8_t* gray)
 {
-    const int B2Y = 1868, G2Y = 9617, R2Y = 4899, shift = 14; /* channel 0 is taken for R */
+    const int wide = g_gray_bits == 15; /* channel 0 is taken for R */
+    const int B2Y = wide ? 3735 : 1868, G2Y = wide ? 19235 : 9617, R2Y = wide ? 9798 : 4899, shift = wide ? 15 : 14;
     for (long i = 0; i < (long)H * W; i++) {
         int r = bgr[3 * i], g = bgr[3 * i + 1], b = bgr[3 * i + 2];
         gray[i] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (shift - 1))) >> shift);

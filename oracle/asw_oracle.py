@@ -77,6 +77,11 @@ def usable_cores():
     return max(1, min(n, max_threads()))
 
 
+def set_gray_bits(bits):
+    """BGR2GRAY constant set of every gray conversion of the oracle: 14 (OpenCV 4.1.0, default) or 15 (later 4.x)."""
+    lib().orc_set_gray_bits(int(bits))
+
+
 def set_box_mode(mode):
     lib().orc_set_box_mode(int(mode))
 
