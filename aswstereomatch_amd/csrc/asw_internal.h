@@ -99,11 +99,11 @@ struct BilateralLaunch {
     int c_begin = 0;  // > 0: only candidates [c_begin, nD); the running minimum is resumed from partE / partD ([H][W])
 };
 // xq form of the classic kernel (k_bilateral_xq.hip): candidates [0, bilateral_xq_candidates()) of a DISPARITY_LEFT, win = 15
-// problem with nD >= bilateral_xq_min_candidates(); writes the running minimum to bestE / bestD for the tail launch
+// problem with at least that many candidates; writes the running minimum to bestE / bestD for the tail launch, or -- when
+// there is no tail (disp != nullptr) -- the disparity itself
 int bilateral_xq_candidates();
-int bilateral_xq_min_candidates();
 int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
-                        const float* lut, float* vol, double* bestE, float* bestD);
+                        const float* lut, float* vol, double* bestE, float* bestD, float* disp);
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 // winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d
 int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp);

@@ -147,7 +147,7 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     // first 125 candidates and this kernel for the tail.  minD <= 48: the leftmost tile must still hold image columns 0..7 when
     // positions clamp to column 0.  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B measurements, tests).
     const char* xq_env = getenv("ASW_BILATERAL_XQ");
-    const bool use_xq = !direct8 && !flip && mp.win == 15 && nD >= bilateral_xq_min_candidates() && mp.minD <= 48 && W >= 64 &&
+    const bool use_xq = !direct8 && !flip && mp.win == 15 && nD >= bilateral_xq_candidates() && mp.minD <= 48 && W >= 64 &&
                         !(xq_env && xq_env[0] == '0');
     if (use_xq) {
         DevBuf& pe = ctx->buf("bil_partE");
@@ -156,11 +156,13 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
         ASW_TRY(pd.ensure((size_t)H * W * sizeof(float)));
         a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = 1;
         a.c_begin = bilateral_xq_candidates();
+        const bool tail = nD > a.c_begin;  // numDisparity = 127 ends exactly at the xq kernel's 128 candidates
         ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-        ASW_TRY(launch_bilateral_xq(ctx->stream, a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol, a.partE, a.partD));
-        ASW_TRY(launch_bilateral(ctx->stream, a));
+        ASW_TRY(launch_bilateral_xq(ctx->stream, a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol, a.partE, a.partD,
+                                    tail ? nullptr : a.disp));
+        if (tail) ASW_TRY(launch_bilateral(ctx->stream, a));
         ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-        ctx->timing.aggregate_launches = 2;
+        ctx->timing.aggregate_launches = tail ? 2 : 1;
         return ASW_OK;
     }
     if ((size_t)H * W <= (size_t)1 << 20) {  // small frames only: scratch for the grid.z split of the disparity range

@@ -21,10 +21,16 @@
 //     left : wL(x, tap column kx)   for the 64 pixels        -> ring of 5 tap columns in LDS (a column is used for 4 steps)
 //     right: wR(q, tap column K-b)  for the 188 positions    -> b = (q - Q) mod 4 is a property of the position, so the buffer of
 //            step K holds, per position, exactly the tap column that position's units consume at step K (double buffered)
-// i.e. 7.4 weight evaluations per thread and step instead of 33 with wave-private staging, one workgroup barrier per step
-// (18 steps of 15 rows), no cost tile, gray tiles as f64 in LDS.  Candidates c = d - minD in [0, 125) are finished here (WTA
-// partial + volume); the tail [125, nD) is left to k_asw_bilateral, which resumes from this kernel's running minimum.
+// i.e. 7.5 weight evaluations per thread and step instead of 33 with wave-private staging, one workgroup barrier per step
+// (18 steps of 15 rows), no cost tile, gray tiles as f64 in LDS.
+// Block j = 0 holds six units with d < minD (a < b) and a block j = 32 would hold exactly six units with c = d - minD < 128
+// in the same slots (c = 128 + a - b): the j = 0 threads run those instead ("wrapped" units: second position base qrel2,
+// second right gray), so the 512 threads finish candidates [0, 128) with no idle unit.  The tail [128, nD) -- one candidate
+// at the reference's numDisparity = 128, whose range is inclusive (M.cpp:1021,1074) -- is left to k_asw_bilateral, which
+// resumes from this kernel's running minimum.
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include "asw_internal.h"
 
@@ -34,13 +40,13 @@ constexpr int HH = 7;                     // half window
 constexpr int KS = 2 * HH + 1;            // 15
 constexpr int PXW = 64;                   // pixels per workgroup
 constexpr int NWAVE = 8;
-constexpr int NJ = 4 * NWAVE;             // position blocks per workgroup
-constexpr int NPOS = PXW + 4 * (NJ - 1);  // 188 right-image positions a workgroup touches
+constexpr int NJ = 4 * NWAVE;             // position blocks per workgroup (+ the wrapped units of block NJ)
+constexpr int NPOS = PXW + 4 * NJ;        // 192 right-image positions a workgroup touches: [posmin, posmin + 191]
 constexpr int LWC = PXW + 2 * HH;         // left tile columns  [x0 - 7, x0 + 70]
-constexpr int RWC = NPOS + 2 * HH;        // right tile columns [posmin - 7, posmax + 7]
+constexpr int RWC = NPOS + 2 * HH;        // right tile columns [posmin - 7, posmin + 198]
 constexpr int NSTEP = KS + 3;             // 18 steps: unit row b runs b tap columns behind
 constexpr int RING = 5;                   // tap columns of left weights kept (4 in use + the one being staged)
-constexpr int NFIN = 4 * NJ - 3;          // 125 candidates are complete for all four pixels of a group
+constexpr int NFIN = 4 * NJ;              // candidates [0, 128) are finished by this kernel
 constexpr int NCELLCOL = NSTEP + 3;       // cell-table columns kx = -3 .. 17
 
 // LDS layout (bytes)
@@ -49,18 +55,19 @@ constexpr int OFF_RD = OFF_LD + KS * LWC * 8;           // double [KS][RWC]   ri
 constexpr int OFF_WL = OFF_RD + KS * RWC * 8;           // float  [RING][KS][PXW]
 constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;    // float  [2][KS][NPOS]
 constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;      // u8     [KS][LW8]
-constexpr int LW8 = 80, RW8 = 204;                      // u8 row strides (multiples of 4)
+constexpr int LW8 = 80, RW8 = 208;                      // u8 row strides (multiples of 4)
 constexpr int OFF_R8 = OFF_L8 + KS * LW8;
-constexpr int OFF_CELL = OFF_R8 + KS * RW8;             // u32 [NCELLCOL * KS]: packed cell table (variant bit 1)
-constexpr int LDS_TOTAL = OFF_CELL + NCELLCOL * KS * 4; // 80 880 B: two workgroups per CU
-constexpr int OFF_E64 = 0;                              // epilogue: double [NFIN][PXW] = 64 000 B over the dead tiles
-constexpr int OFF_PART = NFIN * PXW * 8;                // epilogue: per-part WTA partials, {double E; float d}[NWAVE][PXW]
+constexpr int OFF_CELL = OFF_R8 + KS * RW8;             // u16 [NCELLCOL * KS]: packed cell table
+constexpr int LDS_TOTAL = (OFF_CELL + NCELLCOL * KS * 2 + 15) / 16 * 16;  // 81 280 B: two workgroups per CU
+constexpr int OFF_E64 = 0;                              // epilogue: double [NFIN][PXW] = 65 536 B over the dead tiles
+constexpr int OFF_PART = NFIN * PXW * 8;                // epilogue: per-part WTA partials, double E[NWAVE][PXW], float d[NWAVE][PXW]
 static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
-static_assert(OFF_PART + NWAVE * PXW * 16 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
+static_assert(OFF_PART + NWAVE * PXW * 12 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
 static_assert(OFF_RD % 16 == 0 && OFF_WL % 16 == 0 && OFF_WR % 16 == 0 && (KS * NPOS * 4) % 16 == 0 && (NPOS * 4) % 16 == 0, "b128 alignment");
 
 struct XqParams {
     int H, W, minD;
+    int tile0;  // first 64-pixel tile of this launch (interior tiles and border tiles are separate launches)
 };
 
 __device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned idx)
@@ -68,26 +75,21 @@ __device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned 
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lut) + (idx << 2));
 }
 
-// Stage the weights step `Kn` consumes: left tap column Kn (ring slot Kn % RING) and the right buffer Kn & 1.
-// Wave w evaluates window rows ky = w and w + 8; cells[(kx + 3) * KS + ky] = {dxw, dyw, class * 256, -}: the direction the
-// reference BUILT weight map i for (transposed w.r.t. the sample it is applied to), all-zero class for the
-// skipped cell and for kx outside the window.
-// VAR bit 1: the cell table is read from LDS, packed as (dxw + 8) | (dyw + 8) << 4 | class << 8 (one LDS round trip instead of
-// a global one in front of the LUT gather).
-template <int VAR>
-__device__ __forceinline__ int4 cell_at(const int4* __restrict__ cells, const unsigned char* smem, int idx)
+// packed cell table in LDS: (dxw + 8) | (dyw + 8) << 4 | class << 8
+__device__ __forceinline__ void cell_at(const unsigned char* smem, int idx, int& dxw, int& dyw, int& cls256)
 {
-    if constexpr ((VAR & 2) != 0) {
-        const uint32_t u = reinterpret_cast<const uint32_t*>(smem + OFF_CELL)[idx];
-        return make_int4((int)(u & 15u) - 8, (int)((u >> 4) & 15u) - 8, (int)(u >> 8) << 8, 0);
-    } else {
-        return cells[idx];
-    }
+    const uint32_t u = reinterpret_cast<const uint16_t*>(smem + OFF_CELL)[idx];
+    dxw = (int)(u & 15u) - 8;
+    dyw = (int)((u >> 4) & 15u) - 8;
+    cls256 = (int)(u >> 8) << 8;
 }
 
-template <int VAR>
-__device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ cells, const float* __restrict__ lut,
-                                              unsigned char* smem, int wave, int lane, int ctrL, int pclamp_lo, int pclamp_hi)
+// Stage the weights step `Kn` consumes: left tap column Kn (ring slot Kn % RING) and the right buffer Kn & 1.
+// Wave w evaluates window rows ky = w and w + 8.  Cell (kx, ky) -> {dxw, dyw, class}: the direction the reference BUILT
+// weight map i for (transposed w.r.t. the sample it is applied to), all-zero class for the skipped cell and
+// for kx outside the window.
+__device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ lut, unsigned char* smem, int wave, int lane,
+                                              int ctrL, int pclamp_lo, int pclamp_hi)
 {
     const uint8_t* sL8 = smem + OFF_L8;
     const uint8_t* sR8 = smem + OFF_R8;
@@ -97,36 +99,38 @@ __device__ __forceinline__ void stage_weights(int Kn, const int4* __restrict__ c
     for (int rr = 0; rr < 2; rr++) {
         const int ky = wave + 8 * rr;
         if (ky >= KS) break;  // wave-uniform
+        int dxw, dyw, cls;
         if (Kn < KS) {        // left column Kn exists
-            const int4 ci = cell_at<VAR>(cells, smem, (Kn + 3) * KS + ky);  // uniform index
-            const int nb = sL8[(HH + ci.y) * LW8 + (lane + HH + ci.x)];
-            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctrL, ci.z);
+            cell_at(smem, (Kn + 3) * KS + ky, dxw, dyw, cls);
+            const int nb = sL8[(HH + dyw) * LW8 + (lane + HH + dxw)];
+            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctrL, cls);
             sWL[ky * PXW + lane] = lut_at(lut, idx);
         }
 #pragma unroll
-        for (int r3 = 0; r3 < 3; r3++) {
+        for (int r3 = 0; r3 < NPOS / 64; r3++) {
             const int p = lane + 64 * r3;
-            if (p < NPOS) {
-                const int b = p & 3;  // posmin == Q (mod 4): the unit row a position belongs to is a property of the position
-                const int4 ci = cell_at<VAR>(cells, smem, (Kn - b + 3) * KS + ky);
-                // the weight is evaluated AT max(0, x - d) (M.cpp:1105); its neighbour is clamped from there (tile columns are
-                // replicate-clamped, so adding the direction needs no further clamp)
-                const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
-                const int ctr = sR8[HH * RW8 + pc];
-                const int nb = sR8[(HH + ci.y) * RW8 + pc + ci.x];
-                const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctr, ci.z);
-                sWR[ky * NPOS + p] = lut_at(lut, idx);
-            }
+            const int b = p & 3;  // posmin == Q (mod 4): the unit row a position belongs to is a property of the position
+            cell_at(smem, (Kn - b + 3) * KS + ky, dxw, dyw, cls);
+            // the weight is evaluated AT max(0, x - d) (M.cpp:1105); its neighbour is clamped from there (tile columns are
+            // replicate-clamped, so adding the direction needs no further clamp)
+            const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
+            const int ctr = sR8[HH * RW8 + pc];
+            const int nb = sR8[(HH + dyw) * RW8 + pc + dxw];
+            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctr, cls);
+            sWR[ky * NPOS + p] = lut_at(lut, idx);
         }
     }
 }
 
 // One step: window rows ky = 0..14 of tap column K - b for every active unit row b (BLO <= b <= BHI).
-//   EDGE = false: the workgroup's windows never clamp at the right image border: one right gray per step.
+//   EDGE = false: the workgroup's windows never clamp at the right image border: one right gray per step (two with the
+//                 wrapped units).
 //   EDGE = true : per-diagonal sample columns (lc = min(x + kx - 7, W-1), rc = lc - d), computed once per step.
+// Units with a < b take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block j = 0, where they
+// are the wrapped units of block 32).
 template <int K, bool EDGE>
-__device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int xabs, int dbase, int W, int x0,
-                                         int posmin, double (&num)[4][4], double (&den)[4][4])
+__device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
+                                         int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
 {
     constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;  // kx = K - b <= 14
     constexpr int BHI = K < 3 ? K : 3;                  // kx = K - b >= 0
@@ -140,36 +144,48 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     if constexpr (EDGE) {
 #pragma unroll
         for (int dl = DLO; dl <= DHI; dl++) {
-            const int lc = min(xabs + dl + K - HH, W - 1);        // clamped sample column (left clamp: by the tile)
-            const int rc = lc - (dbase + dl);                     // max(0, .) by the tile
+            const int lc = min(xabs + dl + K - HH, W - 1);                  // clamped sample column (left clamp: by the tile)
+            const int rc = lc - ((dl < 0 ? dbase2 : dbase) + dl);           // max(0, .) by the tile
             iL[dl + 3] = min(max(lc - (x0 - HH), 0), LWC - 1);
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
         }
     }
     const double* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
     const double* pr = sRd + qrel + K;    // tile column of Q + K - 7
+    const double* pr2 = sRd + qrel2 + K;
     const float* pwl = sWL + 4 * g;
     const float* pwr = sWR + qrel;
+    const float* pwr2 = sWR + qrel2;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ky++) {
         double c[7];
         if constexpr (!EDGE) {
             const double gr = pr[ky * RWC];
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - gr;
+            for (int dl = (DLO > 0 ? DLO : 0); dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - gr;
+            if constexpr (DLO < 0) {
+                const double gr2 = pr2[ky * RWC];
+#pragma unroll
+                for (int dl = DLO; dl <= (DHI < -1 ? DHI : -1); dl++) c[dl + 3] = pl[ky * LWC + dl] - gr2;
+            }
         } else {
 #pragma unroll
             for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
         }
         const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * NPOS);
         const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
+        float wr2[4] = {0.0f, wr4.y, wr4.z, wr4.w};
+        if constexpr (BHI >= 1) {  // some active unit has a < b
+            const float4 w2 = *reinterpret_cast<const float4*>(pwr2 + ky * NPOS);
+            wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
+        }
 #pragma unroll
         for (int b = BLO; b <= BHI; b++) {
             const float4 wl4 = *reinterpret_cast<const float4*>(pwl + (((K - b) % RING) * KS + ky) * PXW);
             const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
 #pragma unroll
             for (int a = 0; a < 4; a++) {
-                const float ab = wl[a] * wr[b];                                   // f32 product, M.cpp:1104-1105
+                const float ab = wl[a] * (a < b ? wr2[b] : wr[b]);                // f32 product, M.cpp:1104-1105
                 const double abd = (double)ab;
                 num[a][b] = __builtin_fma(abd, __builtin_fabs(c[a - b + 3]), num[a][b]);  // exact product: == num + ab*|c|
                 den[a][b] = den[a][b] + abd;                                      // M.cpp:1107-1108
@@ -178,33 +194,22 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     }
 }
 
-template <bool EDGE, int VAR>
-__device__ __forceinline__ void run_all_steps(unsigned char* smem, const int4* __restrict__ cells, const float* __restrict__ lut,
-                                              int wave, int lane, int g, int qrel, int xabs, int dbase, int W, int x0, int posmin,
-                                              int ctrL, int pclamp_lo, int pclamp_hi, double (&num)[4][4], double (&den)[4][4])
-{
-#define ASW_XQ_STEP(K)                                                                                   \
-    if ((K) + 1 < NSTEP) stage_weights<VAR>((K) + 1, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi); \
-    run_step<(K), EDGE>(smem, g, qrel, xabs, dbase, W, x0, posmin, num, den);                            \
-    __syncthreads();
-    ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
-    ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
-    ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
-#undef ASW_XQ_STEP
-}
-
-// grid (ceil(W / 64), H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W]; bestE / bestD: [H][W]
-// running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150), to be resumed by the tail launch.
-template <int VAR>
+// grid (tiles of this launch, H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W].
+// bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
+// launch to resume from; disp (when there is no tail): the disparity itself.
+template <bool EDGE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
-    const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD)
+    const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
+    float* __restrict__ disp)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
+    // static: the LDS base is then a compile-time 0 and folds into the instructions' offset fields (with the dynamic-LDS
+    // symbol every address in the step loop carried its own "v_add_u32 v, <base>, v": 6 of 78 VALU instructions)
+    __shared__ __align__(16) unsigned char smem[LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
-    const int x0 = blockIdx.x * PXW, y = blockIdx.y;
-    const int posmin = x0 - p.minD - 4 * (NJ - 1);
+    const int x0 = (p.tile0 + blockIdx.x) * PXW, y = blockIdx.y;
+    const int posmin = x0 - p.minD - 4 * NJ;
 
     // ---- gray tiles, replicate-clamped (M.cpp:1059-1060, 1101-1106), as bytes (weight staging) and as f64 (cost samples)
     {
@@ -226,24 +231,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             sR8[r * RW8 + c] = (uint8_t)v;
             sRd[r * RWC + c] = (double)v;
         }
-        if constexpr ((VAR & 2) != 0) {
-            uint32_t* sCell = reinterpret_cast<uint32_t*>(smem + OFF_CELL);
-            for (int i = tid; i < NCELLCOL * KS; i += 512) {
-                const int4 ci = cells[i];
-                sCell[i] = (uint32_t)(ci.x + 8) | ((uint32_t)(ci.y + 8) << 4) | ((uint32_t)(ci.z >> 8) << 8);
-            }
+        uint16_t* sCell = reinterpret_cast<uint16_t*>(smem + OFF_CELL);
+        for (int i = tid; i < NCELLCOL * KS; i += 512) {
+            const int4 ci = cells[i];
+            sCell[i] = (uint16_t)((uint32_t)(ci.x + 8) | ((uint32_t)(ci.y + 8) << 4) | ((uint32_t)(ci.z >> 8) << 8));
         }
     }
     __syncthreads();
 
-    // lane -> (pixel group g, position block jl).  VAR bit 0: g's low three bits from the lane's low three bits and its bit 3
-    // from lane bit 5, so that the sixteen lanes one ds_read_b128 services together hold eight distinct g's (the f64 gray
-    // reads are 32 B apart per g: g and g + 8 share a bank)
-    const int g = (VAR & 1) ? ((lane & 7) | ((lane >> 2) & 8)) : (lane & 15);
-    const int jl = 4 * wave + ((VAR & 1) ? ((lane >> 3) & 3) : (lane >> 4));
-    const int qrel = 4 * g + 4 * (NJ - 1 - jl);            // Q - posmin, Q = x0 + 4g - minD - 4 jl
+    // lane -> (pixel group g, position block jl): g's low three bits from the lane's low three bits and its bit 3 from lane bit
+    // 5, so that the sixteen lanes one ds_read_b128 services together hold eight distinct g's (the f64 gray reads are 32 B
+    // apart per g: g and g + 8 share a bank; measured: 2.9e9 -> 0.9e9 conflict cycles per frame)
+    const int g = (lane & 7) | ((lane >> 2) & 8);
+    const int jl = 4 * wave + ((lane >> 3) & 3);
+    const int qrel = 4 * g + 4 * (NJ - jl);                // Q - posmin, Q = x0 + 4g - minD - 4 jl
+    const int qrel2 = jl == 0 ? 4 * g : qrel;              // block 32's positions for the wrapped units (a < b) of block 0
     const int xabs = x0 + 4 * g;                           // X
     const int dbase = p.minD + 4 * jl;                     // d of the diagonal a == b
+    const int dbase2 = jl == 0 ? p.minD + 4 * NJ : dbase;
     const int ctrL = smem[OFF_L8 + HH * LW8 + lane + HH];  // this lane's pixel as the centre of left weights it stages
     // positions are clamped into the image before the weight is looked up: max(0, x - d) (and <= W-1 for the lanes of a
     // partial tile, whose results are discarded)
@@ -255,24 +260,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int b = 0; b < 4; b++) { num[a][b] = 0.0; den[a][b] = 0.0; }
 
-    stage_weights<VAR>(0, cells, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
+    stage_weights(0, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
     __syncthreads();
-    // windows of in-image pixels reach the right border when x0 + 63 + 7 > W - 1
-    if (x0 + PXW - 1 + HH <= W - 1)
-        run_all_steps<false, VAR>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
-    else
-        run_all_steps<true, VAR>(smem, cells, lut, wave, lane, g, qrel, xabs, dbase, W, x0, posmin, ctrL, pclamp_lo, pclamp_hi, num, den);
+#define ASW_XQ_STEP(KK)                                                                                     \
+    if ((KK) + 1 < NSTEP) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);           \
+    run_step<(KK), EDGE>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);                  \
+    __syncthreads();
+    ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
+    ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
+    ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
+#undef ASW_XQ_STEP
     // (the last step ended with a barrier: the tiles are dead)
 
-    // ---- E = num / den (M.cpp:1111) -> LDS [candidate][pixel]; rows >= NFIN are incomplete (their other pixels belong to
-    // position blocks beyond this launch) and are recomputed by the tail launch
+    // ---- E = num / den (M.cpp:1111) -> LDS [candidate][pixel]
     double* sE = reinterpret_cast<double*>(smem + OFF_E64);
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int c = 4 * jl + a - b;
-            if (c >= 0 && c < NFIN) sE[c * PXW + 4 * g + a] = num[a][b] / den[a][b];
+            const int c = (a < b ? dbase2 : dbase) - p.minD + a - b;  // in [0, 128) for every unit
+            sE[c * PXW + 4 * g + a] = num[a][b] / den[a][b];
         }
     __syncthreads();
     // ---- WTA (strict '<' while d ascends) and volume: thread -> (pixel, 16 consecutive candidates)
@@ -281,8 +288,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     double be = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
     float bd = 0.0f;
     if (x < W) {
-        const int c1 = min(16 * part + 16, NFIN);
-        for (int c = 16 * part; c < c1; c++) {
+        for (int c = 16 * part; c < 16 * part + 16; c++) {
             const double E = sE[c * PXW + px];
             if (vol) vol[((size_t)c * H + y) * W + x] = (float)E;
             if (E < be) { be = E; bd = (float)(p.minD + c); }
@@ -301,28 +307,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const double eq = sPE[q * PXW + tid];
             if (eq < e) { e = eq; d = sPD[q * PXW + tid]; }
         }
-        bestE[(size_t)y * W + x] = e;
-        bestD[(size_t)y * W + x] = d;
+        if (disp) {
+            disp[(size_t)y * W + x] = d;
+        } else {
+            bestE[(size_t)y * W + x] = e;
+            bestD[(size_t)y * W + x] = d;
+        }
     }
 }
 
 }  // namespace
 
 int bilateral_xq_candidates() { return NFIN; }
-int bilateral_xq_min_candidates() { return 4 * NJ; }  // every unit of the launch must be a real candidate: nD >= 128
 
-// cells: int4[21 * 15] (see stage_weights); lut: float[ncls][256] with an all-zero class.
+// cells: int4[21 * 15] {dxw, dyw, class * 256, -} per window cell, kx = -3..17; lut: float[ncls][256] with an all-zero class.
+// disp != nullptr: the launch covers the whole candidate range (nD == 128): write the disparity; else bestE / bestD.
 int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
-                        const float* lut, float* vol, double* bestE, float* bestD)
+                        const float* lut, float* vol, double* bestE, float* bestD, float* disp)
 {
-    XqParams p{H, W, minD};
-    int var = 3;
-    if (const char* e = getenv("ASW_XQ_VARIANT")) var = atoi(e) & 3;  // measurement hook: bit 0 lane map, bit 1 cell table in LDS
-    auto kern = var == 0 ? k_asw_bilateral_xq<0> : var == 1 ? k_asw_bilateral_xq<1> : var == 2 ? k_asw_bilateral_xq<2> : k_asw_bilateral_xq<3>;
-    // per device (the batch scheduler drives several from one process): set on every launch, it is a table write
-    ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    dim3 grid((W + PXW - 1) / PXW, H);
-    hipLaunchKernelGGL(kern, grid, dim3(512), LDS_TOTAL, s, p, gL, gR, cells, lut, vol, bestE, bestD);
+    const int ntiles = (W + PXW - 1) / PXW;
+    // tiles whose windows (of in-image pixels) stay left of the right border: x0 + 63 + 7 <= W - 1
+    const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;
+    auto ki = k_asw_bilateral_xq<false>;
+    auto ke = k_asw_bilateral_xq<true>;
+    if (n_int > 0) {
+        XqParams p{H, W, minD, 0};
+        hipLaunchKernelGGL(ki, dim3(n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
+    }
+    if (ntiles > n_int) {
+        XqParams p{H, W, minD, n_int};
+        hipLaunchKernelGGL(ke, dim3(ntiles - n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
+    }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

@@ -511,3 +511,57 @@ def test_left_right_check(ctx, oracle):
     assert np.array_equal(got, oracle.lr_check(a, b, 1.0, -2.0)[0])
     with pytest.raises(asw.AswError):
         ctx.leftRightCheck(a, b, -1.0)
+
+
+# ---------------------------------------------------------------- VERDICT r01 item 4 (b), (c)
+def test_gray_constant_sets_are_self_consistent_gpu_vs_oracle(oracle):
+    """the 14-bit BGR2GRAY constants (OpenCV 4.1.0, default) and the 15-bit set of later releases behind ONE
+    switch in the oracle and in the library; with either set the GPU path equals the oracle bit for bit."""
+    L, R, _ = make_pair(30, 70, 10, seed=15, block=10)
+    c = asw.Context(0)
+    try:
+        for bits in (15, 14):
+            c.set_gray_bits(bits)
+            oracle.set_gray_bits(bits)
+            assert np.array_equal(c.bgr2gray(L), oracle.bgr2gray(L))
+            d, v = c.computeAdaptiveWeight(L, R, 30, 20, LEFT, 7, 0, 10, return_cost_volume=True)
+            rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 7, 0, 10, want_vol=True)
+            assert rc == 0 and np.array_equal(v, vw) and np.array_equal(d, dw), bits
+            assert np.array_equal(np.stack(c.getCostSAD(L, R, LEFT, 7, 0, 10)), oracle.cost_sad(L, R, 0, 7, 0, 10)[1]), bits
+            assert np.array_equal(np.stack(c.computeNCC_costs(L, R, LEFT, 5, 0, 6, normalized=False)),
+                                  oracle.cost_ncc(L, R, 0, 5, 0, 6, raw=True)[1], equal_nan=True), bits
+            d, v = c.computeAdaptiveWeight_BLO1(L, R, LEFT, 0.015, 5, 0, 6, return_cost_volume=True)
+            rc, dw, vw = oracle.asw_blo1(L, R, 0, 0.015, 5, 0, 6, want_vol=True)
+            fin = np.isfinite(vw)
+            assert rc == 0 and np.array_equal(v[fin], vw[fin]) and np.array_equal(d, dw), bits
+        g14, g15 = oracle.bgr2gray(L), None
+        oracle.set_gray_bits(15)
+        g15 = oracle.bgr2gray(L)
+        assert not np.array_equal(g14, g15)   # the switch does something
+    finally:
+        oracle.set_gray_bits(14)
+        c.close()
+    with pytest.raises(asw.AswError):
+        asw.Context(0).set_gray_bits(16)
+
+
+def test_guided_paths_vs_opencv_literal_box_sums(ctx, oracle):
+    """orc_set_box_mode(1): the oracle's box filter in OpenCV's literal RowSum / ColumnSum sliding form (the reference's own
+    arithmetic on finite data).  The kernels (vertical sliding + horizontal direct sums) must agree with it within the same
+    tolerance as with the canonical window sums, and pick the same disparities."""
+    L, R, _ = make_pair(120, 260, 24, seed=16)
+    oracle.set_box_mode(1)
+    try:
+        for name, fo, fg in (("guided2", oracle.asw_guided2, ctx.computeAdaptiveWeight_GuidedF_2),
+                             ("guided", oracle.asw_guided, ctx.computeAdaptiveWeight_GuidedF)):
+            rc, dw, vw = fo(L, R, 0, 1e-6, 15, 0, 24, want_vol=True)
+            d, v = fg(L, R, LEFT, 1e-6, 15, 0, 24, return_cost_volume=True)
+            assert rc == 0 and np.all(np.abs(v - vw) <= 1e-4 * np.abs(vw) + 1e-7), name
+            assert np.array_equal(d, dw), (name, int((d != dw).sum()))
+        P = np.random.default_rng(17).random((120, 260), dtype=np.float32)
+        for guide in (L, np.concatenate([L, R], axis=2)):
+            rc, qw = oracle.guided_filter(guide, P, 15, 1e-6)
+            assert rc == 0 and np.all(np.abs(ctx.getGuidedFilter(guide, P, 15, 1e-6) - qw) <= 1e-4 * np.abs(qw) + 1e-7)
+        assert np.array_equal(np.stack(ctx.getCostSAD(L, R, LEFT, 15, 0, 24)), oracle.cost_sad(L, R, 0, 15, 0, 24)[1])  # integer sums: exact in any order
+    finally:
+        oracle.set_box_mode(0)
