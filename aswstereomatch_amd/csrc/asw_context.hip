@@ -87,6 +87,13 @@ extern "C" int asw_create(int device_id, asw_ctx** out)
             delete c;
             return ASW_ERR_HIP;
         }
+    bool ok = true;
+    for (int i = 0; i < 2; i++) ok = ok && hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 3; i++) ok = ok && hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        asw_destroy(c);
+        return ASW_ERR_HIP;
+    }
     *out = c;
     return ASW_OK;
 }
@@ -108,6 +115,13 @@ extern "C" void asw_destroy(asw_ctx* ctx)
     ctx->wm_wd.release();
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 3; i++)
+        if (ctx->aux_ev[i]) (void)hipEventDestroy(ctx->aux_ev[i]);
+    for (int i = 0; i < 2; i++)
+        if (ctx->aux[i]) {
+            (void)hipStreamSynchronize(ctx->aux[i]);
+            (void)hipStreamDestroy(ctx->aux[i]);
+        }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

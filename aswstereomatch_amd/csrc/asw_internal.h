@@ -70,6 +70,10 @@ struct asw_ctx {
     double wm_rate_r = -1, wm_rate_s = -1;
     int wm_win = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // total start/stop, aggregate start/stop
+    // side streams for small launches that are independent of a method's main kernel (border tiles and the one-candidate tail
+    // of the classic bilateral method: 0.5 ms each when serialised, latency-bound) + fork / join events
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
     asw_timing timing = {0, 0, 0, 0};
     DevBuf& buf(const char* name) { return scratch[name]; }
 };
@@ -96,14 +100,16 @@ struct BilateralLaunch {
     double* partE;  // optional scratch [max_slices][H][W]: per-slice winners when the d range is split over grid.z
     float* partD;
     int max_slices;
-    int c_begin = 0;  // > 0: only candidates [c_begin, nD); the running minimum is resumed from partE / partD ([H][W])
+    int c_begin = 0;  // > 0: only candidates [c_begin, nD)
+    int resume = 0;   // 1: the running minimum starts from partE / partD ([H][W]) instead of DBL_MAX
+    int out_slice = -1;  // >= 0: write this launch's winners to slice out_slice of partE / partD (merged later) instead of disp
 };
 // xq form of the classic kernel (k_bilateral_xq.hip): candidates [0, bilateral_xq_candidates()) of a DISPARITY_LEFT, win = 15
 // problem with at least that many candidates; writes the running minimum to bestE / bestD for the tail launch, or -- when
 // there is no tail (disp != nullptr) -- the disparity itself
 int bilateral_xq_candidates();
-int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
-                        const float* lut, float* vol, double* bestE, float* bestD, float* disp);
+int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
+                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp);
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 // winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d
 int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp);

@@ -152,17 +152,31 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     if (use_xq) {
         DevBuf& pe = ctx->buf("bil_partE");
         DevBuf& pd = ctx->buf("bil_partD");
-        ASW_TRY(pe.ensure((size_t)H * W * sizeof(double)));
-        ASW_TRY(pd.ensure((size_t)H * W * sizeof(float)));
-        a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = 1;
+        const size_t plane = (size_t)H * W;
+        ASW_TRY(pe.ensure(2 * plane * sizeof(double)));
+        ASW_TRY(pd.ensure(2 * plane * sizeof(float)));
+        a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = 2;
         a.c_begin = bilateral_xq_candidates();
         const bool tail = nD > a.c_begin;  // numDisparity = 127 ends exactly at the xq kernel's 128 candidates
         ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-        ASW_TRY(launch_bilateral_xq(ctx->stream, a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol, a.partE, a.partD,
-                                    tail ? nullptr : a.disp));
-        if (tail) ASW_TRY(launch_bilateral(ctx->stream, a));
+        // fork: border tiles and the tail are independent of the interior launch (they write other pixels / another slice of the
+        // per-slice winners); on side streams they overlap it instead of adding two latency-bound 0.5 ms launches to the frame
+        ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[0], ctx->stream));
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->aux_ev[0], 0));
+        ASW_TRY(launch_bilateral_xq(ctx->stream, ctx->aux[0], a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol,
+                                    a.partE, a.partD, tail ? nullptr : a.disp));
+        ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[1], ctx->aux[0]));
+        if (tail) {
+            ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->aux_ev[0], 0));
+            a.out_slice = 1;  // candidates [128, nD) -> slice 1; the xq launches fill slice 0
+            ASW_TRY(launch_bilateral(ctx->aux[1], a));
+            ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[2], ctx->aux[1]));
+            ASW_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_ev[2], 0));
+        }
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));  // join
+        if (tail) ASW_TRY(launch_merge_slices(ctx->stream, a.partE, a.partD, 2, plane, a.disp));  // strict '<', ascending d
         ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-        ctx->timing.aggregate_launches = tail ? 2 : 1;
+        ctx->timing.aggregate_launches = tail ? 4 : 2;
         return ASW_OK;
     }
     if ((size_t)H * W <= (size_t)1 << 20) {  // small frames only: scratch for the grid.z split of the disparity range

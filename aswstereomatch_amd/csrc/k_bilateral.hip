@@ -42,8 +42,9 @@ struct BilParams {
     int H, W, h, minD, nD, ntaps;
     int flip;  // 1: the problem is mirrored in x (DISPARITY_RIGHT = DISPARITY_LEFT on mirrored, swapped images)
     int cand_per_z;  // candidates per grid.z slice (multiple of 16); small images split the d range over grid.z
-    int c_begin;     // first candidate of this launch; > 0: the tail of a range whose head k_asw_bilateral_xq has done --
-                     // the running minimum is then resumed from partE / partD ([H][W], grid.z == 1)
+    int c_begin;     // first candidate of this launch; > 0: the tail of a range whose head k_asw_bilateral_xq does
+    int resume;      // 1: the running minimum is resumed from partE / partD ([H][W], grid.z == 1)
+    int out_slice;   // >= 0 (grid.z == 1): winners go to slice out_slice of partE / partD (merged later) instead of disp
 };
 
 constexpr __host__ __device__ int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
     double bestE = 1.7976931348623157e308;  // numeric_limits<double>::max(), M.cpp:1037
     float bestD = 0.0f;
-    if (p.c_begin > 0) {  // resume the strict-'<' scan where the head launch stopped (ascending d is preserved)
+    if (p.resume) {  // resume the strict-'<' scan where the head launch stopped (ascending d is preserved)
         const int xr = x0 + (tid & 63), yr = y0 + (tid >> 6);
         if (xr < W && yr < H) {
             const size_t o = (size_t)yr * W + (p.flip ? W - 1 - xr : xr);
@@ -302,11 +303,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
     if (x < W && y < H) {
         const size_t o = (size_t)y * W + (p.flip ? W - 1 - x : x);
-        if (gridDim.z == 1) {
+        if (gridDim.z == 1 && p.out_slice < 0) {
             disp[o] = bestD;
         } else {  // per-slice winners; k_merge_slices picks the first strict minimum in ascending d
-            partE[(size_t)blockIdx.z * H * W + o] = bestE;
-            partD[(size_t)blockIdx.z * H * W + o] = bestD;
+            const int z = gridDim.z == 1 ? p.out_slice : (int)blockIdx.z;
+            partE[(size_t)z * H * W + o] = bestE;
+            partD[(size_t)z * H * W + o] = bestD;
         }
     }
 }
@@ -331,8 +333,8 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
 {
     BilParams p;
     p.H = a.H; p.W = a.W; p.h = a.win / 2; p.minD = a.minD; p.nD = a.nD; p.ntaps = a.ntaps; p.flip = a.flip;
-    p.c_begin = a.c_begin;
-    if (a.c_begin < 0 || a.c_begin >= a.nD || (a.c_begin > 0 && !(a.partE && a.partD))) return ASW_ERR_BAD_ARGUMENT;
+    p.c_begin = a.c_begin; p.resume = a.resume; p.out_slice = a.out_slice;
+    if (a.c_begin < 0 || a.c_begin >= a.nD || ((a.resume || a.out_slice >= 0) && !(a.partE && a.partD))) return ASW_ERR_BAD_ARGUMENT;
     const Layout lay(p.h, G);
     if (lay.total > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     auto kern = k_asw_bilateral<HH, G, WPE>;
@@ -344,7 +346,7 @@ int launch_t(hipStream_t s, const BilateralLaunch& a)
     // grid.z in multiples of 16 until there are ~2048 workgroups, and merge the per-slice winners afterwards.
     const int tiles = grid.x * grid.y, chunks16 = (a.nD - a.c_begin + 15) / 16;
     int nz = 1;
-    if (a.c_begin == 0 && a.partE && a.partD && tiles < 2048) nz = std::min(chunks16, std::min(a.max_slices, (2048 + tiles - 1) / tiles));
+    if (a.c_begin == 0 && !a.resume && a.out_slice < 0 && a.partE && a.partD && tiles < 2048) nz = std::min(chunks16, std::min(a.max_slices, (2048 + tiles - 1) / tiles));
     const int chunks_per_z = (chunks16 + nz - 1) / nz;
     nz = (chunks16 + chunks_per_z - 1) / chunks_per_z;
     p.cand_per_z = chunks_per_z * 16;

@@ -128,7 +128,9 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
 //   EDGE = true : per-diagonal sample columns (lc = min(x + kx - 7, W-1), rc = lc - d), computed once per step.
 // Units with a < b take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block j = 0, where they
 // are the wrapped units of block 32).
-template <int K, bool EDGE>
+// WRAPW: this wavefront holds the threads of block j = 0 (wave 0).  Elsewhere qrel2 == qrel and the second loads are skipped.
+// ALIGN: read the 7 left grays through 16-byte aligned ds_read_b128 (one spare double when the first index is odd).
+template <int K, bool EDGE, bool WRAPW, bool ALIGN>
 __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                          int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
 {
@@ -150,7 +152,10 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
         }
     }
-    const double* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
+    // first left column of the step is 4g + K + DLO: its parity is that of K + DLO
+    constexpr int SH = (ALIGN && ((K + DLO) & 1)) ? 1 : 0;   // start one double earlier -> even index -> 16-byte aligned
+    constexpr int NLD = (DHI - DLO + 1 + SH + 1) / 2 * 2;    // doubles loaded (even count)
+    const double* pl = sLd + 4 * g + K + DLO - SH;
     const double* pr = sRd + qrel + K;    // tile column of Q + K - 7
     const double* pr2 = sRd + qrel2 + K;
     const float* pwl = sWL + 4 * g;
@@ -160,22 +165,30 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     for (int ky = 0; ky < KS; ky++) {
         double c[7];
         if constexpr (!EDGE) {
-            const double gr = pr[ky * RWC];
+            double gl[NLD];
+            if constexpr (ALIGN) {
 #pragma unroll
-            for (int dl = (DLO > 0 ? DLO : 0); dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - gr;
-            if constexpr (DLO < 0) {
-                const double gr2 = pr2[ky * RWC];
+                for (int i = 0; i < NLD; i += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(__builtin_assume_aligned(pl + ky * LWC + i, 16));
+                    gl[i] = v.x; gl[i + 1] = v.y;
+                }
+            } else {
 #pragma unroll
-                for (int dl = DLO; dl <= (DHI < -1 ? DHI : -1); dl++) c[dl + 3] = pl[ky * LWC + dl] - gr2;
+                for (int i = 0; i < DHI - DLO + 1; i++) gl[i] = pl[ky * LWC + i];
             }
+            const double gr = pr[ky * RWC];
+            double gr2 = gr;
+            if constexpr (WRAPW && DLO < 0) gr2 = pr2[ky * RWC];
+#pragma unroll
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = gl[dl - DLO + SH] - (dl < 0 ? gr2 : gr);
         } else {
 #pragma unroll
             for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
         }
         const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * NPOS);
         const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
-        float wr2[4] = {0.0f, wr4.y, wr4.z, wr4.w};
-        if constexpr (BHI >= 1) {  // some active unit has a < b
+        float wr2[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
+        if constexpr ((WRAPW || EDGE) && BHI >= 1) {  // some active unit has a < b
             const float4 w2 = *reinterpret_cast<const float4*>(pwr2 + ky * NPOS);
             wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
         }
@@ -194,10 +207,25 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     }
 }
 
+template <bool EDGE, bool WRAPW, bool ALIGN>
+__device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* __restrict__ lut, int wave, int lane, int ctrL,
+                                              int pclamp_lo, int pclamp_hi, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
+                                              int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
+{
+#define ASW_XQ_STEP(KK)                                                                                        \
+    if ((KK) + 1 < NSTEP) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);          \
+    run_step<(KK), EDGE, WRAPW, ALIGN>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);    \
+    __syncthreads();
+    ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
+    ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
+    ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
+#undef ASW_XQ_STEP
+}
+
 // grid (tiles of this launch, H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W].
 // bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
 // launch to resume from; disp (when there is no tail): the disparity itself.
-template <bool EDGE>
+template <bool EDGE, int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
@@ -262,14 +290,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     stage_weights(0, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
     __syncthreads();
-#define ASW_XQ_STEP(KK)                                                                                     \
-    if ((KK) + 1 < NSTEP) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);           \
-    run_step<(KK), EDGE>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);                  \
-    __syncthreads();
-    ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
-    ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
-    ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
-#undef ASW_XQ_STEP
+    // wave 0 holds the threads of block j = 0 (the wrapped units): its steps load the second right weights / gray; ONE branch
+    // around the whole step sequence (a branch per step made the register allocator spill 488 VGPRs)
+    if (EDGE || !(VAR & 2) || wave == 0)
+        run_all_steps<EDGE, true, (VAR & 1) != 0>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+                                                   x0, posmin, num, den);
+    else
+        run_all_steps<EDGE, false, (VAR & 1) != 0>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+                                                    x0, posmin, num, den);
     // (the last step ended with a barrier: the tiles are dead)
 
     // ---- E = num / den (M.cpp:1111) -> LDS [candidate][pixel]
@@ -322,21 +350,24 @@ int bilateral_xq_candidates() { return NFIN; }
 
 // cells: int4[21 * 15] {dxw, dyw, class * 256, -} per window cell, kx = -3..17; lut: float[ncls][256] with an all-zero class.
 // disp != nullptr: the launch covers the whole candidate range (nD == 128): write the disparity; else bestE / bestD.
-int launch_bilateral_xq(hipStream_t s, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
-                        const float* lut, float* vol, double* bestE, float* bestD, float* disp)
+// s_border: stream of the border-tile launch (may equal s; a side stream lets the 1/30 of the tiles overlap the main launch)
+int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
+                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp)
 {
     const int ntiles = (W + PXW - 1) / PXW;
     // tiles whose windows (of in-image pixels) stay left of the right border: x0 + 63 + 7 <= W - 1
     const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;
-    auto ki = k_asw_bilateral_xq<false>;
-    auto ke = k_asw_bilateral_xq<true>;
+    int var = 3;
+    if (const char* e = getenv("ASW_XQ_VARIANT")) var = atoi(e) & 3;  // measurement hook: bit 0 aligned gray reads, bit 1 wrapped loads in wave 0 only
+    auto ki = var == 0 ? k_asw_bilateral_xq<false, 0> : var == 1 ? k_asw_bilateral_xq<false, 1> : var == 2 ? k_asw_bilateral_xq<false, 2> : k_asw_bilateral_xq<false, 3>;
+    auto ke = k_asw_bilateral_xq<true, 0>;
     if (n_int > 0) {
         XqParams p{H, W, minD, 0};
         hipLaunchKernelGGL(ki, dim3(n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
     }
     if (ntiles > n_int) {
         XqParams p{H, W, minD, n_int};
-        hipLaunchKernelGGL(ke, dim3(ntiles - n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
+        hipLaunchKernelGGL(ke, dim3(ntiles - n_int, H), dim3(512), 0, s_border, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
     }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
