@@ -274,6 +274,7 @@ struct StatsSplit {
 // box(I_c), box(I_c*I_c) -> meanI_c, den_c = (corrI_c - meanI_c^2) + eps      (M.cpp:2778, 2796-2799, 2846)
 template <int C, int W0, bool SHIFT>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
 struct StatsSrc {
+    static const char* band_env() { return "ASW_BAND_STATS"; }
     GuideAccT<SHIFT> g;
     typedef typename GuideAccT<SHIFT>::Col Col;
     struct Raw { uint32_t u[C / 3]; };
@@ -346,6 +347,7 @@ template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
 template <int C, bool SHIFT>
 struct ABSrc {
+    static const char* band_env() { return "ASW_BAND_AB"; }
     GuideAccT<SHIFT> g;
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
@@ -445,6 +447,7 @@ struct ABDst {
 // box(a_c), box(b) -> q = sum_c box(a_c)*I_c + box(b)                           (M.cpp:2849-2852)
 template <int C>
 struct QSrc {
+    static const char* band_env() { return "ASW_BAND_Q"; }
     const float* ab;
     int H, W;
     static constexpr int AS = ABStride<C>::value;
@@ -499,6 +502,7 @@ struct QDst {
 
 // getCostSAD_d (M.cpp:2442-2503): |grayL - grayR shifted| as f32, box mean
 struct SadSrc {
+    static const char* band_env() { return "ASW_BAND_SAD"; }
     const uint8_t* gl;
     const uint8_t* gr;
     int W, minD, disp_type;
@@ -519,6 +523,7 @@ struct SadSrc {
 };
 // plain 8U plane as f32 (boxFilter(8U -> CV_32F) of getInputImgNCC, M.cpp:785-786)
 struct U8Src {
+    static const char* band_env() { return "ASW_BAND_U8"; }
     const uint8_t* img;
     int W;
     struct Col { const uint8_t* p; };
@@ -548,6 +553,10 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     // warm-up rows (1080p D=128 GuidedF_2, a/b + q pass: 16 rows 5.53 ms, 20..32 rows 5.43-5.50, 48 rows 5.79, 64 rows 6.09,
     // 128 rows 6.24, 270 rows 8.15); the single-channel launches (SAD cost, BLO1) are best at 64
     int band = NP >= 4 ? 32 : 64;
+    if (const char* e = getenv(Src::band_env())) {  // measurement hook (tools/sweep_guided_bands.sh): rows per band of this pass
+        const int b = atoi(e);
+        if (b >= 2) band = b;
+    }
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
     // A launch with too few wavefronts to fill the chip (guide statistics of one slice: 578 at 1080p, 72 at 640x360) is bound by
     // the latency of its serial row walk, not by throughput: shorter bands mean shorter walks and more wavefronts, and the
