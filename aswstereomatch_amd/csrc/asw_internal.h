@@ -185,9 +185,14 @@ int launch_pack_bgrx(hipStream_t s, const uint8_t* bgr, int H, int W, uint32_t* 
 int launch_geodesic_weights_u16(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, uint16_t* planes);
 int launch_geodesic_weights_f32(hipStream_t s, const uint32_t* img, int H, int W, int win, int iter, float* planes);
 int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, int cells, float* out);
+// c_begin / out_slice: only candidates [c_begin, nD), winners to slice out_slice of partE / partD (-1: to disp)
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
                         int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE /* optional
-                        scratch [8][H][W] */, float* partD);
+                        scratch [8][H][W] */, float* partD, int c_begin = 0, int out_slice = -1);
+// xq form (k_geodesic_xq.hip): one pass = candidates [cbase, cbase + 16 * nwave), nwave = 8 or 4, DISPARITY_LEFT, win = 15
+int geodesic_xq_pass_candidates(int nwave);
+int launch_geodesic_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
+                       const uint16_t* wR, int H, int W, int minD, int cbase, float* vol, double* outE, float* outD);
 
 // ---- weighted median (k_wmedian.hip) ----
 int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,

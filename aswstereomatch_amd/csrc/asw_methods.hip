@@ -424,7 +424,41 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
         ASW_TRY(pd.ensure((size_t)8 * plane * sizeof(float)));
         partE = pe.as<double>(); partD = pd.as<float>();
     }
-    if (!flip)
+    // Long candidate ranges of the 15x15 DISPARITY_LEFT case run as passes of the xq kernel (128 / 64 candidates each) plus
+    // k_asw_geodesic for what is left (< 64 candidates); every pass leaves its winners in one slice, merged at the end with
+    // the reference's strict '<' in ascending d.  ASW_GEODESIC_XQ=0 forces the one-kernel path.
+    const char* gxq_env = getenv("ASW_GEODESIC_XQ");
+    if (!flip && mp.win == 15 && nD >= geodesic_xq_pass_candidates(4) && W >= 64 && !(gxq_env && gxq_env[0] == '0')) {
+        const int nslices_max = nD / 64 + 2;
+        DevBuf& pe = ctx->buf("bil_partE");
+        DevBuf& pd = ctx->buf("bil_partD");
+        ASW_TRY(pe.ensure((size_t)nslices_max * plane * sizeof(double)));
+        ASW_TRY(pd.ensure((size_t)nslices_max * plane * sizeof(float)));
+        double* sE = pe.as<double>();
+        float* sD = pd.as<float>();
+        float* vol = keep_volume ? f->vol.as<float>() : nullptr;
+        ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[0], ctx->stream));  // fork: border tiles and the tail run beside the passes
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->aux_ev[0], 0));
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->aux_ev[0], 0));
+        int cb = 0, ns = 0;
+        for (int nw = 8; nw >= 4; nw /= 2)
+            while (nD - cb >= geodesic_xq_pass_candidates(nw)) {
+                ASW_TRY(launch_geodesic_xq(ctx->stream, ctx->aux[0], nw, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(),
+                                           wr.as<uint16_t>(), H, W, mp.minD, cb, vol, sE + (size_t)ns * plane, sD + (size_t)ns * plane));
+                cb += geodesic_xq_pass_candidates(nw);
+                ns++;
+            }
+        if (cb < nD) {
+            ASW_TRY(launch_asw_geodesic(ctx->aux[1], pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
+                                        mp.win, mp.minD, nD, 0, vol, f->disp.as<float>(), sE, sD, cb, ns));
+            ns++;
+        }
+        ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[1], ctx->aux[0]));
+        ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[2], ctx->aux[1]));
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));  // join
+        ASW_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_ev[2], 0));
+        ASW_TRY(launch_merge_slices(ctx->stream, sE, sD, ns, plane, f->disp.as<float>()));
+    } else if (!flip)
         ASW_TRY(launch_asw_geodesic(ctx->stream, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
                                     mp.win, mp.minD, nD, 0, keep_volume ? f->vol.as<float>() : nullptr, f->disp.as<float>(),
                                     partE, partD));

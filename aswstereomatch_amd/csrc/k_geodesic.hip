@@ -148,6 +148,8 @@ struct GeoParams {
     int H, W, win, minD, nD;
     int flip;  // 1: mirrored problem (DISPARITY_RIGHT): images / weight planes are read at W-1-x, window columns reversed
     int cand_per_z;  // candidates per grid.z slice (multiple of 16): small frames split the d range over grid.z
+    int c_begin;     // first candidate of this launch (> 0: the tail of a range whose head k_asw_geodesic_xq covers)
+    int out_slice;   // >= 0 (grid.z == 1): winners go to slice out_slice of partE / partD (merged later) instead of disp
 };
 
 template <int DC, int GDC>
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     double bestE = 1.7976931348623157e308;
     float bestD = 0.0f;
-    int c0 = blockIdx.z * p.cand_per_z;  // this workgroup's candidate range: all of it, or one grid.z slice for small frames
+    int c0 = p.c_begin + blockIdx.z * p.cand_per_z;  // this workgroup's candidate range: all of it, or one grid.z slice for small frames
     const int cEnd = min(p.nD, c0 + p.cand_per_z);
     if constexpr (GDC >= 16)
         for (; c0 + 16 <= cEnd; c0 += 16) geo_chunk<16, GDC>(p, imgR, wL, wR, vol, smem, c0, bestE, bestD);
@@ -319,11 +321,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int x = x0 + (tid & 63), y = y0 + (tid >> 6);
     if (x < p.W && y < p.H) {
         const size_t o = (size_t)y * p.W + (p.flip ? p.W - 1 - x : x);
-        if (gridDim.z == 1) {
+        if (gridDim.z == 1 && p.out_slice < 0) {
             disp[o] = bestD;
         } else {  // per-slice winners, merged by launch_merge_slices
-            partE[(size_t)blockIdx.z * p.H * p.W + o] = bestE;
-            partD[(size_t)blockIdx.z * p.H * p.W + o] = bestD;
+            const int z = gridDim.z == 1 ? p.out_slice : (int)blockIdx.z;
+            partE[(size_t)z * p.H * p.W + o] = bestE;
+            partD[(size_t)z * p.H * p.W + o] = bestD;
         }
     }
 }
@@ -397,9 +400,9 @@ int launch_geo_t(hipStream_t s, GeoParams p, const uint32_t* imgL, const uint32_
     dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH);
     // frames with few tiles (KITTI: 1880 for 1024 resident workgroups) split the candidate range over grid.z in
     // multiples of 16 until there are ~4096 workgroups; a second tiny launch merges the per-slice winners
-    const int tiles = grid.x * grid.y, chunks16 = (p.nD + 15) / 16;
+    const int tiles = grid.x * grid.y, chunks16 = (p.nD - p.c_begin + 15) / 16;
     int nz = 1;
-    if (partE && partD && tiles < 4096) nz = std::min(chunks16, std::min(8, (4096 + tiles - 1) / tiles));
+    if (p.c_begin == 0 && p.out_slice < 0 && partE && partD && tiles < 4096) nz = std::min(chunks16, std::min(8, (4096 + tiles - 1) / tiles));
     const int chunks_per_z = (chunks16 + nz - 1) / nz;
     nz = (chunks16 + chunks_per_z - 1) / chunks_per_z;
     p.cand_per_z = chunks_per_z * 16;
@@ -412,9 +415,11 @@ int launch_geo_t(hipStream_t s, GeoParams p, const uint32_t* imgL, const uint32_
 }  // namespace
 
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
-                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE, float* partD)
+                        int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE, float* partD,
+                        int c_begin, int out_slice)
 {
-    GeoParams p{H, W, win, minD, nD, flip, 0};
+    if (c_begin < 0 || c_begin >= nD || (out_slice >= 0 && !(partE && partD))) return ASW_ERR_BAD_ARGUMENT;
+    GeoParams p{H, W, win, minD, nD, flip, 0, c_begin, out_slice};
     // 16-wide d-chunks: 25 KB of LDS at win 15 (45 KB at win 35)
     if (geo_lds_bytes<16>(win) <= 160 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp, partE, partD);
     return ASW_ERR_BAD_ARGUMENT;
