@@ -134,16 +134,25 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
         for (int b = BLO; b <= BHI; b++) {
             const float4 wl4 = *reinterpret_cast<const float4*>(pwl + (((K - b) % RING) * KS + ky) * PXW);
             const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
+            float ab[4];
+            if constexpr (!(WRAPW || EDGE)) {  // one multiplier per unit row: two packed products
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 lo = {wl[0], wl[1]}, hi = {wl[2], wl[3]}, w = {wr[b], wr[b]};
+                const f32x2 p0 = lo * w, p1 = hi * w;
+                ab[0] = p0.x; ab[1] = p0.y; ab[2] = p1.x; ab[3] = p1.y;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; a++) ab[a] = wl[a] * (a < b ? wr2[b] : wr[b]);   // f32
+            }
 #pragma unroll
             for (int a = 0; a < 4; a++) {
-                const float ab = wl[a] * (a < b ? wr2[b] : wr[b]);   // f32
                 // f32 (M.cpp:1488-1490).  As one v_mul_f32: left to itself the compiler pairs these products into
                 // v_pk_mul_f32 and pays for it with ~29 v_mov per step to line the (ab, c) operands up in even-aligned
                 // register pairs (135 VALU instructions per step instead of ~110; every one costs an issue slot)
                 float abc;
-                asm("v_mul_f32 %0, %1, %2" : "=v"(abc) : "v"(ab), "v"(c[a - b + 3]));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(abc) : "v"(ab[a]), "v"(c[a - b + 3]));
                 num[a][b] = num[a][b] + (double)abc;
-                den[a][b] = den[a][b] + (double)ab;                  // M.cpp:1491-1492
+                den[a][b] = den[a][b] + (double)ab[a];               // M.cpp:1491-1492
             }
         }
     }
