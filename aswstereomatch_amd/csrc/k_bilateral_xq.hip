@@ -88,13 +88,17 @@ __device__ __forceinline__ void cell_at(const unsigned char* smem, int idx, int&
 // Wave w evaluates window rows ky = w and w + 8.  Cell (kx, ky) -> {dxw, dyw, class}: the direction the reference BUILT
 // weight map i for (transposed w.r.t. the sample it is applied to), all-zero class for the skipped cell and
 // for kx outside the window.
-__device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ lut, unsigned char* smem, int wave, int lane,
-                                              int ctrL, int pclamp_lo, int pclamp_hi)
+// Split in two so that the LUT gathers of step Kn are in flight while step Kn - 1 is being accumulated: stage_issue (index
+// pass + gathers, at the top of the step) and stage_commit (LDS writes, in the middle of the step's row loop).  Done in one
+// piece in front of the step, the staging cost 10 % of the kernel for 5 % of its instructions: eight wavefronts waiting for
+// the same two memory round trips (ablation: profiles/r02/ablation_*.csv).
+struct Staged { float v[2][1 + NPOS / 64]; };
+
+__device__ __forceinline__ void stage_issue(int Kn, const float* __restrict__ lut, const unsigned char* smem, int wave, int lane,
+                                            int ctrL, int pclamp_lo, int pclamp_hi, Staged& st)
 {
     const uint8_t* sL8 = smem + OFF_L8;
     const uint8_t* sR8 = smem + OFF_R8;
-    float* sWL = reinterpret_cast<float*>(smem + OFF_WL) + (Kn % RING) * (KS * PXW);
-    float* sWR = reinterpret_cast<float*>(smem + OFF_WR) + (Kn & 1) * (KS * NPOS);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int ky = wave + 8 * rr;
@@ -103,8 +107,7 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
         if (Kn < KS) {        // left column Kn exists
             cell_at(smem, (Kn + 3) * KS + ky, dxw, dyw, cls);
             const int nb = sL8[(HH + dyw) * LW8 + (lane + HH + dxw)];
-            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctrL, cls);
-            sWL[ky * PXW + lane] = lut_at(lut, idx);
+            st.v[rr][0] = lut_at(lut, __builtin_amdgcn_sad_u16(nb, ctrL, cls));
         }
 #pragma unroll
         for (int r3 = 0; r3 < NPOS / 64; r3++) {
@@ -116,10 +119,31 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
             const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
             const int ctr = sR8[HH * RW8 + pc];
             const int nb = sR8[(HH + dyw) * RW8 + pc + dxw];
-            const unsigned idx = __builtin_amdgcn_sad_u16(nb, ctr, cls);
-            sWR[ky * NPOS + p] = lut_at(lut, idx);
+            st.v[rr][1 + r3] = lut_at(lut, __builtin_amdgcn_sad_u16(nb, ctr, cls));
         }
     }
+}
+
+__device__ __forceinline__ void stage_commit(int Kn, unsigned char* smem, int wave, int lane, const Staged& st)
+{
+    float* sWL = reinterpret_cast<float*>(smem + OFF_WL) + (Kn % RING) * (KS * PXW);
+    float* sWR = reinterpret_cast<float*>(smem + OFF_WR) + (Kn & 1) * (KS * NPOS);
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ky = wave + 8 * rr;
+        if (ky >= KS) break;
+        if (Kn < KS) sWL[ky * PXW + lane] = st.v[rr][0];
+#pragma unroll
+        for (int r3 = 0; r3 < NPOS / 64; r3++) sWR[ky * NPOS + lane + 64 * r3] = st.v[rr][1 + r3];
+    }
+}
+
+__device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ lut, unsigned char* smem, int wave, int lane,
+                                              int ctrL, int pclamp_lo, int pclamp_hi)
+{
+    Staged st;
+    stage_issue(Kn, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);
+    stage_commit(Kn, smem, wave, lane, st);
 }
 
 // One step: window rows ky = 0..14 of tap column K - b for every active unit row b (BLO <= b <= BHI).
@@ -129,10 +153,10 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
 // Units with a < b take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block j = 0, where they
 // are the wrapped units of block 32).
 // WRAPW: this wavefront holds the threads of block j = 0 (wave 0).  Elsewhere qrel2 == qrel and the second loads are skipped.
-// ALIGN: read the 7 left grays through 16-byte aligned ds_read_b128 (one spare double when the first index is odd).
-template <int K, bool EDGE, bool WRAPW, bool ALIGN>
-__device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
-                                         int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
+template <int K, bool EDGE, bool WRAPW, bool COMMIT>
+__device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
+                                         int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4], int wave, int lane,
+                                         const Staged& st)
 {
     constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;  // kx = K - b <= 14
     constexpr int BHI = K < 3 ? K : 3;                  // kx = K - b >= 0
@@ -152,10 +176,7 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
         }
     }
-    // first left column of the step is 4g + K + DLO: its parity is that of K + DLO
-    constexpr int SH = (ALIGN && ((K + DLO) & 1)) ? 1 : 0;   // start one double earlier -> even index -> 16-byte aligned
-    constexpr int NLD = (DHI - DLO + 1 + SH + 1) / 2 * 2;    // doubles loaded (even count)
-    const double* pl = sLd + 4 * g + K + DLO - SH;
+    const double* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
     const double* pr = sRd + qrel + K;    // tile column of Q + K - 7
     const double* pr2 = sRd + qrel2 + K;
     const float* pwl = sWL + 4 * g;
@@ -163,24 +184,16 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     const float* pwr2 = sWR + qrel2;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ky++) {
+        if constexpr (COMMIT) {
+            if (ky == KS / 2) stage_commit(K + 1, smem, wave, lane, st);  // the gathers issued before this loop have landed
+        }
         double c[7];
         if constexpr (!EDGE) {
-            double gl[NLD];
-            if constexpr (ALIGN) {
-#pragma unroll
-                for (int i = 0; i < NLD; i += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(__builtin_assume_aligned(pl + ky * LWC + i, 16));
-                    gl[i] = v.x; gl[i + 1] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < DHI - DLO + 1; i++) gl[i] = pl[ky * LWC + i];
-            }
             const double gr = pr[ky * RWC];
             double gr2 = gr;
             if constexpr (WRAPW && DLO < 0) gr2 = pr2[ky * RWC];
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = gl[dl - DLO + SH] - (dl < 0 ? gr2 : gr);
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - (dl < 0 ? gr2 : gr);
         } else {
 #pragma unroll
             for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
@@ -207,15 +220,21 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     }
 }
 
-template <bool EDGE, bool WRAPW, bool ALIGN>
+// ABL (timing experiments only, results are wrong): bit 0 = no weight staging after step 0, bit 1 = no barriers between steps
+template <bool EDGE, bool WRAPW, int ABL>
 __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* __restrict__ lut, int wave, int lane, int ctrL,
                                               int pclamp_lo, int pclamp_hi, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                               int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
 {
+    Staged st;
 #define ASW_XQ_STEP(KK)                                                                                        \
-    if ((KK) + 1 < NSTEP) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);          \
-    run_step<(KK), EDGE, WRAPW, ALIGN>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);    \
-    __syncthreads();
+    if (!(ABL & 1) && (KK) + 1 < NSTEP) {                                                                        \
+        if constexpr (EDGE) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);  /* border tiles: registers are scarcer there */ \
+        else stage_issue((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);                      \
+    }                                                                                                           \
+    run_step<(KK), EDGE, WRAPW, (!EDGE && !(ABL & 1) && (KK) + 1 < NSTEP)>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, \
+                                                                           num, den, wave, lane, st);          \
+    if (!(ABL & 2) || (KK) == NSTEP - 1) __syncthreads();
     ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
     ASW_XQ_STEP(6) ASW_XQ_STEP(7) ASW_XQ_STEP(8) ASW_XQ_STEP(9) ASW_XQ_STEP(10) ASW_XQ_STEP(11)
     ASW_XQ_STEP(12) ASW_XQ_STEP(13) ASW_XQ_STEP(14) ASW_XQ_STEP(15) ASW_XQ_STEP(16) ASW_XQ_STEP(17)
@@ -225,7 +244,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* 
 // grid (tiles of this launch, H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W].
 // bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
 // launch to resume from; disp (when there is no tail): the disparity itself.
-template <bool EDGE, int VAR>
+template <bool EDGE, int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
@@ -292,11 +311,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     // wave 0 holds the threads of block j = 0 (the wrapped units): its steps load the second right weights / gray; ONE branch
     // around the whole step sequence (a branch per step made the register allocator spill 488 VGPRs)
-    if (EDGE || !(VAR & 2) || wave == 0)
-        run_all_steps<EDGE, true, (VAR & 1) != 0>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+    if (EDGE || wave == 0)
+        run_all_steps<EDGE, true, ABL>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                    x0, posmin, num, den);
     else
-        run_all_steps<EDGE, false, (VAR & 1) != 0>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+        run_all_steps<EDGE, false, ABL>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                     x0, posmin, num, den);
     // (the last step ended with a barrier: the tiles are dead)
 
@@ -357,9 +376,9 @@ int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, 
     const int ntiles = (W + PXW - 1) / PXW;
     // tiles whose windows (of in-image pixels) stay left of the right border: x0 + 63 + 7 <= W - 1
     const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;
-    int var = 3;
-    if (const char* e = getenv("ASW_XQ_VARIANT")) var = atoi(e) & 3;  // measurement hook: bit 0 aligned gray reads, bit 1 wrapped loads in wave 0 only
-    auto ki = var == 0 ? k_asw_bilateral_xq<false, 0> : var == 1 ? k_asw_bilateral_xq<false, 1> : var == 2 ? k_asw_bilateral_xq<false, 2> : k_asw_bilateral_xq<false, 3>;
+    int abl = 0;
+    if (const char* e = getenv("ASW_XQ_ABLATE")) abl = atoi(e) & 3;  // timing experiments only (profiles/r02/ablation_*.csv)
+    auto ki = abl == 0 ? k_asw_bilateral_xq<false, 0> : abl == 1 ? k_asw_bilateral_xq<false, 1> : abl == 2 ? k_asw_bilateral_xq<false, 2> : k_asw_bilateral_xq<false, 3>;
     auto ke = k_asw_bilateral_xq<true, 0>;
     if (n_int > 0) {
         XqParams p{H, W, minD, 0};

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Kernel-level profile of the classic bilateral path on the GPU box (1080p D=128 win 15):
 #   /usr/local/graft/bin/gpurun --timeout 600 -- 'bash tools/prof_bilateral.sh <tag> [variants...]'
-# per ASW_XQ_VARIANT: rocprofv3 kernel stats of tools/run_one.py and two SQ counter passes (separate runs, --pmc never
+# per ASW_XQ_ABLATE value (0 = the product; 1 no staging, 2 no barriers, 3 both: timing experiments) or "old": rocprofv3 kernel stats of tools/run_one.py and two SQ counter passes (separate runs, --pmc never
 # combined with other trace domains).  Output: gpurun_out/<tag>/.
 set -e -o pipefail
 TAG=${1:-bil}; shift || true
-VARS=${@:-3}
+VARS=${@:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 SQ_A="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES"
 SQ_B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM"
 for v in $VARS; do
-    export ASW_XQ_VARIANT=$v
+    export ASW_XQ_ABLATE=$v
     if [ "$v" = "old" ]; then export ASW_BILATERAL_XQ=0; else unset ASW_BILATERAL_XQ; fi
     rocprofv3 --kernel-trace --stats -d /tmp/st_$v -o p --output-format csv -- python3 "$ROOT/tools/run_one.py" --alg 2 --reps 5 > "$OUT/stats_$v.log" 2>&1
     cp /tmp/st_$v/p_kernel_stats.csv "$OUT/kernel_stats_var$v.csv"
