@@ -58,15 +58,21 @@ __device__ __forceinline__ uint32_t cdist(uint32_t a, uint32_t b) { return __bui
 
 // Stage the weights step `Kn` consumes (cf. k_bilateral_xq.hip): wave w handles window rows ky = w, w + NWAVE, ...
 // plane of window cell (row ky = j, column kx = i): ky * 15 + kx (M.cpp:1481-1483: j outer, i inner; the order is free here).
+// Split in two (cf. k_bilateral_xq.hip): stage_issue loads the weights of step Kn into registers at the top of step Kn - 1,
+// stage_commit writes them to LDS in the middle of that step's row loop, so the plane loads fly under the accumulation.
 template <int NWAVE>
-__device__ __forceinline__ void stage_weights(int Kn, const uint16_t* __restrict__ wLrow, const uint16_t* __restrict__ wRrow,
-                                              size_t plane, unsigned char* smem, int wave, int lane, int xl, int posmin, int W)
+struct Staged { float v[(KS + NWAVE - 1) / NWAVE][1 + Geo<NWAVE>::NPOS / 64]; };
+
+template <int NWAVE>
+__device__ __forceinline__ void stage_issue(int Kn, const uint16_t* __restrict__ wLrow, const uint16_t* __restrict__ wRrow,
+                                            size_t plane, int wave, int lane, int xl, int posmin, int W, Staged<NWAVE>& st)
 {
     using G = Geo<NWAVE>;
-    float* sWL = reinterpret_cast<float*>(smem + G::OFF_WL) + (Kn % RING) * (KS * PXW);
-    float* sWR = reinterpret_cast<float*>(smem + G::OFF_WR) + (Kn & 1) * (KS * G::NPOS);
-    for (int ky = wave; ky < KS; ky += NWAVE) {  // wave-uniform
-        if (Kn < KS) sWL[ky * PXW + lane] = (float)wLrow[(size_t)(ky * KS + Kn) * plane + xl];
+#pragma unroll
+    for (int it = 0; it < (KS + NWAVE - 1) / NWAVE; it++) {
+        const int ky = wave + NWAVE * it;
+        if (ky >= KS) break;  // wave-uniform
+        if (Kn < KS) st.v[it][0] = (float)wLrow[(size_t)(ky * KS + Kn) * plane + xl];
 #pragma unroll
         for (int r3 = 0; r3 < G::NPOS / 64; r3++) {
             const int p = lane + 64 * r3;
@@ -76,14 +82,40 @@ __device__ __forceinline__ void stage_weights(int Kn, const uint16_t* __restrict
                 const int xr = min(max(posmin + p, 0), W - 1);  // the weight window of max(0, x - d) (M.cpp:1489)
                 w = (float)wRrow[(size_t)(ky * KS + kx) * plane + xr];
             }
-            sWR[ky * G::NPOS + p] = w;
+            st.v[it][1 + r3] = w;
         }
     }
 }
 
-template <int NWAVE, int K, bool EDGE, bool WRAPW>
-__device__ __forceinline__ void run_step(const unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
-                                         int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
+template <int NWAVE>
+__device__ __forceinline__ void stage_commit(int Kn, unsigned char* smem, int wave, int lane, const Staged<NWAVE>& st)
+{
+    using G = Geo<NWAVE>;
+    float* sWL = reinterpret_cast<float*>(smem + G::OFF_WL) + (Kn % RING) * (KS * PXW);
+    float* sWR = reinterpret_cast<float*>(smem + G::OFF_WR) + (Kn & 1) * (KS * G::NPOS);
+#pragma unroll
+    for (int it = 0; it < (KS + NWAVE - 1) / NWAVE; it++) {
+        const int ky = wave + NWAVE * it;
+        if (ky >= KS) break;
+        if (Kn < KS) sWL[ky * PXW + lane] = st.v[it][0];
+#pragma unroll
+        for (int r3 = 0; r3 < G::NPOS / 64; r3++) sWR[ky * G::NPOS + lane + 64 * r3] = st.v[it][1 + r3];
+    }
+}
+
+template <int NWAVE>
+__device__ __forceinline__ void stage_weights(int Kn, const uint16_t* __restrict__ wLrow, const uint16_t* __restrict__ wRrow,
+                                              size_t plane, unsigned char* smem, int wave, int lane, int xl, int posmin, int W)
+{
+    Staged<NWAVE> st;
+    stage_issue<NWAVE>(Kn, wLrow, wRrow, plane, wave, lane, xl, posmin, W, st);
+    stage_commit<NWAVE>(Kn, smem, wave, lane, st);
+}
+
+template <int NWAVE, int K, bool EDGE, bool WRAPW, bool COMMIT>
+__device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
+                                         int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4], int wave, int lane,
+                                         const Staged<NWAVE>& st)
 {
     using G = Geo<NWAVE>;
     constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;
@@ -112,6 +144,9 @@ __device__ __forceinline__ void run_step(const unsigned char* smem, int g, int q
     const float* pwr2 = sWR + qrel2;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ky++) {
+        if constexpr (COMMIT) {
+            if (ky == KS / 2) stage_commit<NWAVE>(K + 1, smem, wave, lane, st);  // the loads issued before this loop have landed
+        }
         float c[7];
         if constexpr (!EDGE) {
             const uint32_t gr = pr[ky * G::RWC];
@@ -163,9 +198,14 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const uint16_
                                               size_t plane, int wave, int lane, int xl, int g, int qrel, int qrel2, int xabs, int dbase,
                                               int dbase2, int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
 {
+    Staged<NWAVE> st;
 #define ASW_GXQ_STEP(KK)                                                                                             \
-    if ((KK) + 1 < NSTEP) stage_weights<NWAVE>((KK) + 1, wLrow, wRrow, plane, smem, wave, lane, xl, posmin, W);      \
-    run_step<NWAVE, (KK), EDGE, WRAPW>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);          \
+    if ((KK) + 1 < NSTEP) {                                                                                          \
+        if constexpr (EDGE) stage_weights<NWAVE>((KK) + 1, wLrow, wRrow, plane, smem, wave, lane, xl, posmin, W);    \
+        else stage_issue<NWAVE>((KK) + 1, wLrow, wRrow, plane, wave, lane, xl, posmin, W, st);                       \
+    }                                                                                                                \
+    run_step<NWAVE, (KK), EDGE, WRAPW, (!EDGE && (KK) + 1 < NSTEP)>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, \
+                                                                    den, wave, lane, st);                            \
     __syncthreads();
     ASW_GXQ_STEP(0) ASW_GXQ_STEP(1) ASW_GXQ_STEP(2) ASW_GXQ_STEP(3) ASW_GXQ_STEP(4) ASW_GXQ_STEP(5)
     ASW_GXQ_STEP(6) ASW_GXQ_STEP(7) ASW_GXQ_STEP(8) ASW_GXQ_STEP(9) ASW_GXQ_STEP(10) ASW_GXQ_STEP(11)
