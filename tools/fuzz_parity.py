@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--fresh-every", type=int, default=300, help="recreate the context every N cases: first-use paths (unallocated tables, scratch growth) get exercised in many orders")
     ap.add_argument("--flat", type=float, default=0.25, help="share of the cases whose images get constant rectangles (flat windows: 0/0 NCC costs, zero variances, ties)")
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
+    ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
+                    "DISPARITY_LEFT, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = asw.Context(0)
@@ -70,6 +72,18 @@ def main():
             L, R = Lp[:, :W], Rp[:, :W]   # non-contiguous views; the oracle wrappers copy them
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
                                 "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck", "resident", "batch"]))
+        if rng.random() < args.xq:
+            method = str(rng.choice(["classic", "geodesic"]))
+            H, W = int(rng.integers(1, 10)), int(rng.integers(64, 420))
+            win, dt = 15, 0
+            minD = int(rng.choice([0, 0, 1, 5, 48, 49, 70])) if method == "classic" else int(rng.choice([0, 0, 2, 33, 130]))
+            numD = int(rng.choice([63, 64, 127, 128, 129, 191, 192, 255, int(rng.integers(63, 300))]))
+            seed = int(rng.integers(0, 1 << 30))
+            L, R, _ = make_pair(H, W, max(2, min(numD, W) // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
+            if rng.random() < 0.3:
+                for img in (L, R):
+                    y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                    img[y0:y0 + int(rng.integers(1, 6)), x0:x0 + int(rng.integers(1, 60))] = rng.integers(0, 256, 3).astype(np.uint8)
         tag = (method, H, W, win, minD, numD, dt, seed)
         if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
             ctx.close()
