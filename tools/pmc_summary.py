@@ -9,7 +9,7 @@ HDR = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "T
        "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 for path in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(path), fieldnames=HDR):
+    for r in (r for r in csv.DictReader(open(path), fieldnames=HDR) if r["Counter_Value"] != "Counter_Value"):
         m = re.search(r"(k_\w+)", r["Kernel_Name"])
         acc[(m.group(1) if m else r["Kernel_Name"][:40], r["VGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(path)
