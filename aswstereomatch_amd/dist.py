@@ -20,7 +20,6 @@ class Group:
     def __init__(self, backend=None, device=None):
         self.rank, self.local_rank, self.world = env_ranks()
         self.dist = None
-        self.cpu = None
         self.device = device
         if self.world > 1:
             import torch.distributed as dist
@@ -32,21 +31,9 @@ class Group:
                 kw["device_id"] = device
             dist.init_process_group(backend=backend or "gloo", rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
-            # a CPU-side group for waits that must not put a spinning RCCL kernel on the devices (bench.py: the ranks
-            # that idle while rank 0 drives every GPU through asw_stereo_match_batch)
-            self.cpu = dist.new_group(backend="gloo") if (backend or "gloo") != "gloo" else None
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
-
-    def cpu_barrier(self):
-        """Barrier that runs on the host only (gloo), whatever the main backend is."""
-        if self.dist is None:
-            return
-        if self.cpu is not None:
-            self.dist.barrier(group=self.cpu)
-        else:
             self.dist.barrier()
 
     def gather_ints(self, value):

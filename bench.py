@@ -11,9 +11,9 @@ timed region and the MAX over ranks of the elapsed time.  Rank 0 prints ONE JSON
 N > 1: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` every process is one
 rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); a bare `python bench.py --gpus N` starts the N
 ranks itself as child processes (launch_ranks: the parent never touches the GPU).  Either way WORLD_SIZE
-must equal --gpus and every rank must find its own GPU, or the run fails loudly.  After the timed region
-rank 0 also drives all N devices from one process through the library's own batch API
-(`asw_stereo_match_batch`, 64 frames, host buffers in and out) and reports it as `batch_api`.
+must equal --gpus and every rank must find its own GPU, or the run fails loudly.  After the timed region the
+ranks leave the process group; rank 0 alone then drives all N devices from one process through the library's
+own batch API (`asw_stereo_match_batch`, 64 frames, host buffers in and out) and reports it as `batch_api`.
 """
 import argparse
 import json
@@ -353,9 +353,16 @@ def main(argv=None):
                                         "unit": "TFLOP/s", "frac": round(tf / F64_PEAK_TFLOPS, 4),
                                         "note": "3 f64 flop per (pixel,d,tap); cvt/f32 work not counted"}
 
+    # The process group has done its job (barrier around the timed region, MAX of the elapsed time): leave it now, all ranks
+    # together.  Ranks other than 0 are finished and free their device; rank 0 goes on alone with the legs that are not part of
+    # `value` -- no collective is pending, so nothing of RCCL can spin on a device meanwhile.
+    group.close()
+    if rank != 0:
+        eng.close()
+        return
+
     # ---- second leg, rank 0 only, after the timed region: the product's own multi-GPU API.  asw_stereo_match_batch shards
-    # --batch-frames frames (host buffers in and out) over ALL --gpus devices from ONE process; the other ranks are idle and
-    # wait on a CPU-side (gloo) barrier so that no RCCL kernel spins on the devices meanwhile.
+    # --batch-frames frames (host buffers in and out) over ALL --gpus devices from ONE process.
     if not args.dry_run and args.batch_frames > 0:
         if rank == 0:
             import aswstereomatch_amd as asw
@@ -377,7 +384,6 @@ def main(argv=None):
                                 "outputs_equal_resident_path": bool(same),
                                 "note": "one process, one host thread + context per device, pageable host buffers in and out "
                                         "(PCIe-inclusive); never the headline value"}
-        group.cpu_barrier()
 
     if rank == 0 and not args.dry_run:
         if world == 1:
@@ -399,7 +405,6 @@ def main(argv=None):
                     out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     eng.close()
-    group.close()
 
 
 if __name__ == "__main__":
