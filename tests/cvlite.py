@@ -166,3 +166,129 @@ def sum_f64_rowmajor(a):
     for v in np.asarray(a, F32).ravel():
         s += float(v)
     return s
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# f3 primitives (reference main.cpp:30-31, 67-89, 97-98), whole-array forms
+# ---------------------------------------------------------------------------------------------------------------------------
+def resize_linear_u8(src, dsize):
+    """resize(src 8UC3, dst, Size(dw, dh)) with INTER_LINEAR: an exact 2x downscale runs as the 2x2 area average; otherwise
+    11-bit coefficient pairs per destination column/row, horizontal pass into int, the truncating 8U vertical pass."""
+    dw, dh = dsize
+    sh, sw = src.shape[:2]
+    s = src.astype(np.int64)
+    if sw == 2 * dw and sh == 2 * dh:
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    scale_x, scale_y = 1.0 / (float(dw) / sw), 1.0 / (float(dh) / sh)
+
+    def taps(n_dst, n_src, scale, clamp_frac):
+        f = ((np.arange(n_dst, dtype=F64) + 0.5) * scale - 0.5).astype(F32)
+        i0 = np.floor(f).astype(np.int64)
+        f = (f - i0.astype(F32)).astype(F32)
+        if clamp_frac:  # x only: the fraction is dropped where the pair would leave the row
+            lo = i0 < 0
+            f[lo] = 0
+            i0[lo] = 0
+            hi = i0 >= n_src - 1
+            f[hi] = 0
+            i0[hi] = n_src - 1
+        c0 = np.rint((F32(1) - f) * F32(2048)).astype(np.int64)
+        c1 = np.rint(f * F32(2048)).astype(np.int64)
+        return i0, c0, c1
+
+    x0, a0, a1 = taps(dw, sw, scale_x, True)
+    x1 = np.minimum(x0 + 1, sw - 1)  # where x0 + 1 == sw the coefficient a1 is 0
+    hor = s[:, x0] * a0[None, :, None] + s[:, x1] * a1[None, :, None]  # [sh][dw][3], S * 2048 where the pair is degenerate
+    y0, b0, b1 = taps(dh, sh, scale_y, False)
+    r0 = hor[np.clip(y0, 0, sh - 1)]
+    r1 = hor[np.clip(y0 + 1, 0, sh - 1)]
+    b0 = b0[:, None, None]
+    b1 = b1[:, None, None]
+    return ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+
+
+def cvtColor_BGR2HSV(bgr):
+    """cvtColor(COLOR_BGR2HSV) on 8U, H in [0, 180): 12-bit reciprocal tables for S and H."""
+    b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    diff = v - np.minimum(np.minimum(b, g), r)
+    idx = np.arange(256, dtype=F64)
+    with np.errstate(divide="ignore"):
+        sdiv = np.where(idx > 0, np.rint((255 << 12) / idx), 0).astype(np.int64)
+        hdiv = np.where(idx > 0, np.rint((180 << 12) / (6.0 * idx)), 0).astype(np.int64)
+    s = (diff * sdiv[v] + 2048) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + 2048) >> 12
+    h = np.where(h < 0, h + 180, h)
+    return np.stack([saturate_u8(h), s.astype(np.uint8), v.astype(np.uint8)], axis=-1)
+
+
+def cvtColor_HSV2BGR(hsv):
+    """cvtColor(COLOR_HSV2BGR) on 8U: to float (H * 6/180, S/255, V/255), the six-sector table, * 255, cvRound."""
+    h = hsv[..., 0].astype(F32) * (F32(6) / F32(180))
+    s = hsv[..., 1].astype(F32) * (F32(1) / F32(255))
+    v = hsv[..., 2].astype(F32) * (F32(1) / F32(255))
+    h = np.where(h >= 6, h - F32(6), h).astype(F32)  # H <= 255 * 6/180 = 8.5: at most one wrap
+    sec = np.floor(h).astype(np.int64)
+    f = (h - sec.astype(F32)).astype(F32)
+    one = F32(1)
+    t0 = v
+    t1 = v * (one - s)
+    t2 = v * (one - s * f)
+    t3 = v * (one - s * (one - f))
+    tab = np.stack([t0, t1, t2, t3], axis=0)
+    order = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    pick = order[sec]  # [...][3] -> which of tab for B, G, R
+    out = np.take_along_axis(tab, np.moveaxis(pick, -1, 0), axis=0)  # [3][...]
+    out = np.where(s[None] == 0, v[None], out)
+    return np.moveaxis(saturate_u8(cvRound_f32(out * F32(255))), 0, -1)
+
+
+def bilateralFilter_u8(src, d, sigma_color, sigma_space):
+    """bilateralFilter(src 8UC1, dst, d, sigmaColor, sigmaSpace, BORDER_REFLECT) (aswStereoMatch.cpp:75,84): circular support
+    of radius d/2 visited in raster order; per tap w = space[k] * colour[|I - I0|] in float; float sums in tap order;
+    cvRound(sum / wsum)."""
+    import math
+    radius = d // 2 if d > 0 else int(round(sigma_space * 1.5))
+    radius = max(radius, 1)
+    gs = -0.5 / (sigma_space * sigma_space)
+    gc = -0.5 / (sigma_color * sigma_color)
+    cw = np.array([math.exp(i * i * gc) for i in range(256)], F64).astype(F32)
+    H, W = src.shape
+    p = copyMakeBorder(src, radius, radius, radius, radius, BORDER_REFLECT).astype(np.int64)
+    c = src.astype(np.int64)
+    acc = np.zeros((H, W), F32)
+    wacc = np.zeros((H, W), F32)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r = math.sqrt(float(i * i + j * j))
+            if r > radius:
+                continue
+            ws = F32(math.exp(r * r * gs))
+            n = p[radius + i:radius + i + H, radius + j:radius + j + W]
+            w = ws * cw[np.abs(n - c)]
+            acc = acc + n.astype(F32) * w
+            wacc = wacc + w
+    return cvRound_f32(acc / wacc).astype(np.uint8)
+
+
+def detail_boost(bgr):
+    """aswStereoMatch.cpp:67-89 on one image: split HSV, V' = V + 2 * (V - bilateral(V)) in saturating u8 Mat arithmetic."""
+    hsv = cvtColor_BGR2HSV(bgr)
+    v = hsv[..., 2]
+    blur = bilateralFilter_u8(v, 7, 10.0, 3.0)
+    detail = np.clip(v.astype(np.int32) - blur.astype(np.int32), 0, 255)  # u8 subtract saturates at 0
+    out = hsv.copy()
+    out[..., 2] = np.clip(v.astype(np.int32) + 2 * detail, 0, 255).astype(np.uint8)
+    return cvtColor_HSV2BGR(out)
+
+
+def disparity_to_u8(disp, normalize=True):
+    """aswStereoMatch.cpp:97-98: convertTo(CV_8UC1) then normalize(0, 255, NORM_MINMAX) on the u8 image."""
+    u = saturate_u8(cvRound_f32(np.asarray(disp, F32)))
+    if not normalize:
+        return u
+    mn, mx = int(u.min()), int(u.max())
+    scale = 255.0 * (1.0 / (mx - mn) if (mx - mn) > np.finfo(F64).eps else 0.0)
+    shift = 0.0 - mn * scale
+    return saturate_u8(cvRound_f32(u.astype(F32) * F32(scale) + F32(shift)))

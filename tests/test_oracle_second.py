@@ -349,3 +349,35 @@ def test_gray_constants_switch(oracle):
     assert v14.shape == v15.shape and not np.array_equal(v14, v15)       # the choice does reach the cost volume
     for bits, e in ((14, (29, 150, 76)), (15, (29, 150, 76))):           # pure B, G, R: both sets round to the same values
         assert tuple(cv.cvtColor_BGR2GRAY(np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8), bits)[0]) == e
+
+
+def test_f3_primitives_second_restatement(oracle):
+    """resize / BGR<->HSV / bilateralFilter / detail boost / u8 output (aswStereoMatch.cpp:30-31, 67-89, 97-98): the numpy
+    whole-array forms of tests/cvlite.py against the per-pixel C oracle, bit for bit."""
+    O = oracle
+    rng = np.random.default_rng(2024)
+    for (sh, sw), (dw, dh) in [((37, 53), (29, 21)), ((40, 64), (32, 20)), ((31, 45), (90, 70)), ((64, 48), (24, 32)),
+                               ((50, 70), (70, 50)), ((9, 13), (5, 4))]:
+        src = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(cv.resize_linear_u8(src, (dw, dh)), O.resize_linear(src, (dw, dh)),
+                                      err_msg=f"resize {sh}x{sw} -> {dh}x{dw}")
+    img = rng.integers(0, 256, (48, 80, 3), dtype=np.uint8)
+    img[:6] = rng.integers(0, 256, (6, 80, 1), dtype=np.uint8)  # grey rows: S = 0, H = 0
+    img[6:12, :, 1] = img[6:12, :, 2]                           # ties between the maxima
+    hsv = cv.cvtColor_BGR2HSV(img)
+    np.testing.assert_array_equal(hsv, O.bgr2hsv(img))
+    every = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 3), np.arange(0, 256, 7), indexing="ij"),
+                     axis=-1).reshape(1, -1, 3).astype(np.uint8)  # includes H >= 180, which HSV2BGR must wrap
+    np.testing.assert_array_equal(cv.cvtColor_HSV2BGR(every), O.hsv2bgr(every))
+    np.testing.assert_array_equal(cv.cvtColor_HSV2BGR(hsv), O.hsv2bgr(hsv))
+    plane = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    smooth = (np.add.outer(np.arange(40), np.arange(56)) * 2 % 256).astype(np.uint8)
+    for pl in (plane, smooth):
+        np.testing.assert_array_equal(cv.bilateralFilter_u8(pl, 7, 10.0, 3.0), O.bilateral_u8(pl, 7, 10.0, 3.0))
+    np.testing.assert_array_equal(cv.detail_boost(img), O.detail_boost(img))
+    disp = (rng.random((30, 40)) * 300 - 20).astype(np.float32)
+    disp[3, 3] = 12.5
+    disp[3, 4] = 13.5
+    for nrm in (True, False):
+        np.testing.assert_array_equal(cv.disparity_to_u8(disp, nrm), O.disparity_to_u8(disp, nrm))
+    np.testing.assert_array_equal(cv.disparity_to_u8(np.full((4, 4), 7, np.float32)), O.disparity_to_u8(np.full((4, 4), 7, np.float32)))
