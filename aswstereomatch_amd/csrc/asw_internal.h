@@ -109,7 +109,7 @@ struct BilateralLaunch {
 // there is no tail (disp != nullptr) -- the disparity itself
 int bilateral_xq_candidates();
 int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
-                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp);
+                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right = false);
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 // winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d
 int launch_merge_slices(hipStream_t s, const double* partE, const float* partD, int nz, size_t plane, float* disp);
@@ -192,7 +192,7 @@ int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* img
 // xq form (k_geodesic_xq.hip): one pass = candidates [cbase, cbase + 16 * nwave), nwave = 8 or 4, DISPARITY_LEFT, win = 15
 int geodesic_xq_pass_candidates(int nwave);
 int launch_geodesic_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
-                       const uint16_t* wR, int H, int W, int minD, int cbase, float* vol, double* outE, float* outD);
+                       const uint16_t* wR, int H, int W, int minD, int cbase, float* vol, double* outE, float* outD, bool right = false);
 
 // ---- weighted median (k_wmedian.hip) ----
 int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, int win, const float* lut2, const float* wd,

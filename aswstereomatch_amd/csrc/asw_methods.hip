@@ -82,7 +82,7 @@ static int ensure_bilateral_tables(asw_ctx* ctx, int kind, int win, double gamma
     // three columns behind the step counter); the all-zero class stands for "no tap": outside the window and the one cell the
     // reference's index arithmetic skips (kernel_x 7, kernel_y 8: M.cpp:1090-1099 jumps from i = 112 to the cell of i + 1).
     std::vector<int4> cells;
-    if (kind == 0 && win == 15 && !mirror) {
+    if (kind == 0 && win == 15) {  // image coordinates, for either direction (the xq kernel does not mirror)
         cells.assign(21 * 15, make_int4(0, 0, zero_cls * 256, 0));
         for (int i = 0; i < nt; i++) {
             const int kx = dxs[i] + h, ky = dys[i] + h;
@@ -143,11 +143,13 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     a.vol = keep_volume ? f->vol.as<float>() : nullptr;
     a.disp = f->disp.as<float>();
     a.partE = nullptr; a.partD = nullptr; a.max_slices = 0;
-    // Long candidate ranges of the reference's own configuration (DISPARITY_LEFT, 15x15) take the xq form of the kernel for the
-    // first 125 candidates and this kernel for the tail.  minD <= 48: the leftmost tile must still hold image columns 0..7 when
-    // positions clamp to column 0.  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B measurements, tests).
+    // Long candidate ranges of the reference's own configuration (15x15, either direction) take the xq form of the kernel for the
+    // first 128 candidates and this kernel for the tail.  The tile of the outermost workgroup must still hold the eight image
+    // columns next to the border its positions clamp to: LEFT minD <= 48 (columns 0..7 in the first tile), RIGHT
+    // x0_last + minD <= W - 1 (columns W-8..W-1 in the last).  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B, tests).
     const char* xq_env = getenv("ASW_BILATERAL_XQ");
-    const bool use_xq = !direct8 && !flip && mp.win == 15 && nD >= bilateral_xq_candidates() && mp.minD <= 48 && W >= 64 &&
+    const bool xq_fits = flip ? (W - 1) / 64 * 64 + mp.minD <= W - 1 : mp.minD <= 48;
+    const bool use_xq = !direct8 && mp.win == 15 && nD >= bilateral_xq_candidates() && mp.minD >= 0 && xq_fits && W >= 64 &&
                         !(xq_env && xq_env[0] == '0');
     if (use_xq) {
         DevBuf& pe = ctx->buf("bil_partE");
@@ -164,7 +166,7 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
         ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[0], ctx->stream));
         ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->aux_ev[0], 0));
         ASW_TRY(launch_bilateral_xq(ctx->stream, ctx->aux[0], a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol,
-                                    a.partE, a.partD, tail ? nullptr : a.disp));
+                                    a.partE, a.partD, tail ? nullptr : a.disp, flip != 0));
         ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[1], ctx->aux[0]));
         if (tail) {
             ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->aux_ev[0], 0));
@@ -424,11 +426,16 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
         ASW_TRY(pd.ensure((size_t)8 * plane * sizeof(float)));
         partE = pe.as<double>(); partD = pd.as<float>();
     }
-    // Long candidate ranges of the 15x15 DISPARITY_LEFT case run as passes of the xq kernel (128 / 64 candidates each) plus
+    // Long candidate ranges of the 15x15 case (either direction) run as passes of the xq kernel (128 / 64 candidates each) plus
     // k_asw_geodesic for what is left (< 64 candidates); every pass leaves its winners in one slice, merged at the end with
     // the reference's strict '<' in ascending d.  ASW_GEODESIC_XQ=0 forces the one-kernel path.
     const char* gxq_env = getenv("ASW_GEODESIC_XQ");
-    if (!flip && mp.win == 15 && nD >= geodesic_xq_pass_candidates(4) && W >= 64 && !(gxq_env && gxq_env[0] == '0')) {
+    if (mp.win == 15 && nD >= geodesic_xq_pass_candidates(4) && W >= 64 && mp.minD >= 0 && !(gxq_env && gxq_env[0] == '0')) {
+        // fixed image (the one the disparity map belongs to) / other image
+        const uint32_t* pf = flip ? pr.as<uint32_t>() : pl.as<uint32_t>();
+        const uint32_t* po = flip ? pl.as<uint32_t>() : pr.as<uint32_t>();
+        const uint16_t* wf = flip ? wr.as<uint16_t>() : wl.as<uint16_t>();
+        const uint16_t* wo = flip ? wl.as<uint16_t>() : wr.as<uint16_t>();
         const int nslices_max = nD / 64 + 2;
         DevBuf& pe = ctx->buf("bil_partE");
         DevBuf& pd = ctx->buf("bil_partD");
@@ -443,14 +450,14 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
         int cb = 0, ns = 0;
         for (int nw = 8; nw >= 4; nw /= 2)
             while (nD - cb >= geodesic_xq_pass_candidates(nw)) {
-                ASW_TRY(launch_geodesic_xq(ctx->stream, ctx->aux[0], nw, pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(),
-                                           wr.as<uint16_t>(), H, W, mp.minD, cb, vol, sE + (size_t)ns * plane, sD + (size_t)ns * plane));
+                ASW_TRY(launch_geodesic_xq(ctx->stream, ctx->aux[0], nw, pf, po, wf, wo, H, W, mp.minD, cb, vol,
+                                           sE + (size_t)ns * plane, sD + (size_t)ns * plane, flip != 0));
                 cb += geodesic_xq_pass_candidates(nw);
                 ns++;
             }
         if (cb < nD) {
-            ASW_TRY(launch_asw_geodesic(ctx->aux[1], pl.as<uint32_t>(), pr.as<uint32_t>(), wl.as<uint16_t>(), wr.as<uint16_t>(), H, W,
-                                        mp.win, mp.minD, nD, 0, vol, f->disp.as<float>(), sE, sD, cb, ns));
+            ASW_TRY(launch_asw_geodesic(ctx->aux[1], pf, po, wf, wo, H, W, mp.win, mp.minD, nD, flip, vol, f->disp.as<float>(), sE, sD,
+                                        cb, ns));
             ns++;
         }
         ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[1], ctx->aux[0]));

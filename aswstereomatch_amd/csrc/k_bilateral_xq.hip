@@ -17,7 +17,8 @@
 // because ab*c is exact: 24-bit x 8-bit significands).
 //
 // Workgroup = one image row x 64 pixels x 32 position blocks (d = minD + 4j + a - b, j < 32): 8 wavefronts, lane -> (pixel
-// group g = lane & 15, position block 4*wave + (lane >> 4)).  All 512 threads share the staged weights of a step:
+// group g, position block 4*wave + ((lane >> 3) & 3)); the lane -> g map is chosen for the LDS banks, see the kernel.  All 512
+// threads share the staged weights of a step:
 //     left : wL(x, tap column kx)   for the 64 pixels        -> ring of 5 tap columns in LDS (a column is used for 4 steps)
 //     right: wR(q, tap column K-b)  for the 188 positions    -> b = (q - Q) mod 4 is a property of the position, so the buffer of
 //            step K holds, per position, exactly the tap column that position's units consume at step K (double buffered)
@@ -28,6 +29,12 @@
 // second right gray), so the 512 threads finish candidates [0, 128) with no idle unit.  The tail [128, nD) -- one candidate
 // at the reference's numDisparity = 128, whose range is inclusive (M.cpp:1021,1074) -- is left to k_asw_bilateral, which
 // resumes from this kernel's running minimum.
+//
+// DISPARITY_RIGHT (M.cpp:1113-1142; RIGHT = true): the fixed image is the right one (the host passes it as gL) and the pair of
+// pixel x is the left-image position q = min(W-1, x + d).  Nothing in the blocking depends on the sign of d: unit (a,b) is
+// still (pixel X+a, position Q+b) with tap column K - b, d = (Q+b) - (X+a) = minD + 4j + b - a, so the dead units of block 0 are
+// those with b < a and the positions run to the right of the tile.  Sample columns clamp the other way round: the tile clamps
+// coincide with the reference's at the right image border, not at the left one, so the border tiles are the first of a row.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -150,10 +157,10 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
 //   EDGE = false: the workgroup's windows never clamp at the right image border: one right gray per step (two with the
 //                 wrapped units).
 //   EDGE = true : per-diagonal sample columns (lc = min(x + kx - 7, W-1), rc = lc - d), computed once per step.
-// Units with a < b take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block j = 0, where they
-// are the wrapped units of block 32).
+// Units with a < b (RIGHT: b < a) take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block
+// j = 0, where they are the wrapped units of block 32).
 // WRAPW: this wavefront holds the threads of block j = 0 (wave 0).  Elsewhere qrel2 == qrel and the second loads are skipped.
-template <int K, bool EDGE, bool WRAPW, bool COMMIT>
+template <int K, bool EDGE, bool WRAPW, bool COMMIT, bool RIGHT>
 __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                          int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4], int wave, int lane,
                                          const Staged& st)
@@ -170,8 +177,10 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
     if constexpr (EDGE) {
 #pragma unroll
         for (int dl = DLO; dl <= DHI; dl++) {
-            const int lc = min(xabs + dl + K - HH, W - 1);                  // clamped sample column (left clamp: by the tile)
-            const int rc = lc - ((dl < 0 ? dbase2 : dbase) + dl);           // max(0, .) by the tile
+            // clamped sample column of the fixed image, then the other image's column from THERE (M.cpp:1101-1106, 1129-1134);
+            // the far clamp of that one (max(0, .) / min(W-1, .)) is the tile's
+            const int lc = min(max(xabs + dl + K - HH, 0), W - 1);
+            const int rc = RIGHT ? lc + ((dl > 0 ? dbase2 : dbase) - dl) : lc - ((dl < 0 ? dbase2 : dbase) + dl);
             iL[dl + 3] = min(max(lc - (x0 - HH), 0), LWC - 1);
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
         }
@@ -191,9 +200,18 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
         if constexpr (!EDGE) {
             const double gr = pr[ky * RWC];
             double gr2 = gr;
-            if constexpr (WRAPW && DLO < 0) gr2 = pr2[ky * RWC];
+            if constexpr (WRAPW && (RIGHT ? DHI > 0 : DLO < 0)) gr2 = pr2[ky * RWC];
+            // the left grays of the step, read as 16-byte aligned pairs from an even tile column (4g, LWC and E0 are even): a
+            // run that starts on an odd column is split by the compiler into ds_read2_b64, which cost four times the LDS cycles
+            // of ds_read_b128 here (8 instead of 4, and 2-way conflicts: their banks are taken mod 32)
+            constexpr int E0 = (K + DLO) & ~1, NP2 = (K + DHI - E0 + 2) / 2;
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            const f64x2* pl2 = reinterpret_cast<const f64x2*>(sLd + 4 * g + E0 + ky * LWC);
+            double glv[2 * NP2];
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = pl[ky * LWC + dl] - (dl < 0 ? gr2 : gr);
+            for (int i = 0; i < NP2; i++) { const f64x2 t = pl2[i]; glv[2 * i] = t.x; glv[2 * i + 1] = t.y; }
+#pragma unroll
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = glv[K + dl - E0] - ((RIGHT ? dl > 0 : dl < 0) ? gr2 : gr);
         } else {
 #pragma unroll
             for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
@@ -201,9 +219,9 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
         const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * NPOS);
         const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
         float wr2[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
-        if constexpr ((WRAPW || EDGE) && BHI >= 1) {  // some active unit has a < b
+        if constexpr ((WRAPW || EDGE) && (RIGHT ? BLO <= 2 : BHI >= 1)) {  // some active unit is a wrapped one
             const float4 w2 = *reinterpret_cast<const float4*>(pwr2 + ky * NPOS);
-            wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
+            wr2[0] = w2.x; wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
         }
 #pragma unroll
         for (int b = BLO; b <= BHI; b++) {
@@ -211,7 +229,7 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
             const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
 #pragma unroll
             for (int a = 0; a < 4; a++) {
-                const float ab = wl[a] * (a < b ? wr2[b] : wr[b]);                // f32 product, M.cpp:1104-1105
+                const float ab = wl[a] * ((RIGHT ? b < a : a < b) ? wr2[b] : wr[b]);  // f32 product, M.cpp:1104-1105
                 const double abd = (double)ab;
                 num[a][b] = __builtin_fma(abd, __builtin_fabs(c[a - b + 3]), num[a][b]);  // exact product: == num + ab*|c|
                 den[a][b] = den[a][b] + abd;                                      // M.cpp:1107-1108
@@ -221,7 +239,7 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
 }
 
 // ABL (timing experiments only, results are wrong): bit 0 = no weight staging after step 0, bit 1 = no barriers between steps
-template <bool EDGE, bool WRAPW, int ABL>
+template <bool EDGE, bool WRAPW, int ABL, bool RIGHT>
 __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* __restrict__ lut, int wave, int lane, int ctrL,
                                               int pclamp_lo, int pclamp_hi, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                               int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
@@ -232,7 +250,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* 
         if constexpr (EDGE) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);  /* border tiles: registers are scarcer there */ \
         else stage_issue((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);                      \
     }                                                                                                           \
-    run_step<(KK), EDGE, WRAPW, (!EDGE && !(ABL & 1) && (KK) + 1 < NSTEP)>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, \
+    run_step<(KK), EDGE, WRAPW, (!EDGE && !(ABL & 1) && (KK) + 1 < NSTEP), RIGHT>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, \
                                                                            num, den, wave, lane, st);          \
     if (!(ABL & 2) || (KK) == NSTEP - 1) __syncthreads();
     ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
@@ -244,7 +262,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* 
 // grid (tiles of this launch, H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W].
 // bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
 // launch to resume from; disp (when there is no tail): the disparity itself.
-template <bool EDGE, int ABL>
+template <bool EDGE, int ABL, bool RIGHT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
     const int x0 = (p.tile0 + blockIdx.x) * PXW, y = blockIdx.y;
-    const int posmin = x0 - p.minD - 4 * NJ;
+    const int posmin = RIGHT ? x0 + p.minD : x0 - p.minD - 4 * NJ;  // == Q (mod 4) either way
 
     // ---- gray tiles, replicate-clamped (M.cpp:1059-1060, 1101-1106), as bytes (weight staging) and as f64 (cost samples)
     {
@@ -291,14 +309,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // apart per g: g and g + 8 share a bank; measured: 2.9e9 -> 0.9e9 conflict cycles per frame)
     const int g = (lane & 7) | ((lane >> 2) & 8);
     const int jl = 4 * wave + ((lane >> 3) & 3);
-    const int qrel = 4 * g + 4 * (NJ - jl);                // Q - posmin, Q = x0 + 4g - minD - 4 jl
-    const int qrel2 = jl == 0 ? 4 * g : qrel;              // block 32's positions for the wrapped units (a < b) of block 0
+    // Q - posmin; LEFT: Q = x0 + 4g - minD - 4 jl, RIGHT: Q = x0 + 4g + minD + 4 jl
+    const int qrel = RIGHT ? 4 * g + 4 * jl : 4 * g + 4 * (NJ - jl);
+    // block 32's positions for the wrapped units of block 0
+    const int qrel2 = jl == 0 ? (RIGHT ? 4 * g + 4 * NJ : 4 * g) : qrel;
     const int xabs = x0 + 4 * g;                           // X
     const int dbase = p.minD + 4 * jl;                     // d of the diagonal a == b
     const int dbase2 = jl == 0 ? p.minD + 4 * NJ : dbase;
     const int ctrL = smem[OFF_L8 + HH * LW8 + lane + HH];  // this lane's pixel as the centre of left weights it stages
-    // positions are clamped into the image before the weight is looked up: max(0, x - d) (and <= W-1 for the lanes of a
-    // partial tile, whose results are discarded)
+    // positions are clamped into the image before the weight is looked up: max(0, x - d) / min(W-1, x + d) (the other bound
+    // only matters for the lanes of a partial tile, whose results are discarded)
     const int pclamp_lo = min(max(0 - posmin, 0), NPOS - 1), pclamp_hi = min(max(W - 1 - posmin, 0), NPOS - 1);
 
     double num[4][4], den[4][4];
@@ -312,10 +332,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // wave 0 holds the threads of block j = 0 (the wrapped units): its steps load the second right weights / gray; ONE branch
     // around the whole step sequence (a branch per step made the register allocator spill 488 VGPRs)
     if (EDGE || wave == 0)
-        run_all_steps<EDGE, true, ABL>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+        run_all_steps<EDGE, true, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                    x0, posmin, num, den);
     else
-        run_all_steps<EDGE, false, ABL>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+        run_all_steps<EDGE, false, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                     x0, posmin, num, den);
     // (the last step ended with a barrier: the tiles are dead)
 
@@ -325,7 +345,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int c = (a < b ? dbase2 : dbase) - p.minD + a - b;  // in [0, 128) for every unit
+            const int c = RIGHT ? (b < a ? dbase2 : dbase) - p.minD + b - a
+                                : (a < b ? dbase2 : dbase) - p.minD + a - b;  // in [0, 128) for every unit
             sE[c * PXW + 4 * g + a] = num[a][b] / den[a][b];
         }
     __syncthreads();
@@ -370,16 +391,33 @@ int bilateral_xq_candidates() { return NFIN; }
 // cells: int4[21 * 15] {dxw, dyw, class * 256, -} per window cell, kx = -3..17; lut: float[ncls][256] with an all-zero class.
 // disp != nullptr: the launch covers the whole candidate range (nD == 128): write the disparity; else bestE / bestD.
 // s_border: stream of the border-tile launch (may equal s; a side stream lets the 1/30 of the tiles overlap the main launch)
+// right: DISPARITY_RIGHT -- gL is then the fixed (right) image's gray plane and gR the left image's.
 int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
-                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp)
+                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right)
 {
     const int ntiles = (W + PXW - 1) / PXW;
+    if (right) {
+        // border tile = the first of a row (windows of x < 7 clamp at column 0); the clamped positions' weight neighbours
+        // (columns W-8 .. W-1) must lie in the last tile's right-gray tile: x0_last + minD <= W - 1
+        if ((ntiles - 1) * PXW + minD > W - 1) return ASW_ERR_BAD_ARGUMENT;
+        XqParams pe{H, W, minD, 0};
+        hipLaunchKernelGGL((k_asw_bilateral_xq<true, 0, true>), dim3(1, H), dim3(512), 0, s_border, pe, gL, gR, cells, lut, vol,
+                           bestE, bestD, disp);
+        if (ntiles > 1) {
+            XqParams pi{H, W, minD, 1};
+            hipLaunchKernelGGL((k_asw_bilateral_xq<false, 0, true>), dim3(ntiles - 1, H), dim3(512), 0, s, pi, gL, gR, cells, lut,
+                               vol, bestE, bestD, disp);
+        }
+        ASW_HIP_TRY(hipGetLastError());
+        return ASW_OK;
+    }
     // tiles whose windows (of in-image pixels) stay left of the right border: x0 + 63 + 7 <= W - 1
     const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;
     int abl = 0;
     if (const char* e = getenv("ASW_XQ_ABLATE")) abl = atoi(e) & 3;  // timing experiments only (profiles/r02/ablation_*.csv)
-    auto ki = abl == 0 ? k_asw_bilateral_xq<false, 0> : abl == 1 ? k_asw_bilateral_xq<false, 1> : abl == 2 ? k_asw_bilateral_xq<false, 2> : k_asw_bilateral_xq<false, 3>;
-    auto ke = k_asw_bilateral_xq<true, 0>;
+    auto ki = abl == 0 ? k_asw_bilateral_xq<false, 0, false> : abl == 1 ? k_asw_bilateral_xq<false, 1, false>
+            : abl == 2 ? k_asw_bilateral_xq<false, 2, false> : k_asw_bilateral_xq<false, 3, false>;
+    auto ke = k_asw_bilateral_xq<true, 0, false>;
     if (n_int > 0) {
         XqParams p{H, W, minD, 0};
         hipLaunchKernelGGL(ki, dim3(n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);

@@ -15,6 +15,10 @@
 // long range is cut into passes of 128 / 64 candidates (8 / 4 wavefronts) whose winners are merged like grid.z slices.
 // Against k_asw_geodesic (16 candidates per chunk) the weight planes are read once per 128 / 64 candidates instead of once
 // per 16, and from LDS by 512 / 256 threads instead of per tile row.
+//
+// DISPARITY_RIGHT (M.cpp:1498-1520; RIGHT = true): fixed image = the right one (passed as imgL / wL), positions
+// q = min(W-1, x + d) run to the right, d = d0 + 4j + b - a, dead / wrapped units are those with b < a, and the border tile is
+// the first of a row (k_bilateral_xq.hip has the derivation).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -112,7 +116,7 @@ __device__ __forceinline__ void stage_weights(int Kn, const uint16_t* __restrict
     stage_commit<NWAVE>(Kn, smem, wave, lane, st);
 }
 
-template <int NWAVE, int K, bool EDGE, bool WRAPW, bool COMMIT>
+template <int NWAVE, int K, bool EDGE, bool WRAPW, bool COMMIT, bool RIGHT>
 __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                          int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4], int wave, int lane,
                                          const Staged<NWAVE>& st)
@@ -130,8 +134,9 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
     if constexpr (EDGE) {
 #pragma unroll
         for (int dl = DLO; dl <= DHI; dl++) {
-            const int lc = min(xabs + dl + K - HH, W - 1);                  // clamped sample column (left clamp: by the tile)
-            const int rc = lc - ((dl < 0 ? dbase2 : dbase) + dl);           // max(0, .) by the tile
+            // clamped sample column of the fixed image, the other image's column from there; its far clamp is the tile's
+            const int lc = min(max(xabs + dl + K - HH, 0), W - 1);
+            const int rc = RIGHT ? lc + ((dl > 0 ? dbase2 : dbase) - dl) : lc - ((dl < 0 ? dbase2 : dbase) + dl);
             iL[dl + 3] = min(max(lc - (x0 - HH), 0), LWC - 1);
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), G::RWC - 1);
         }
@@ -151,9 +156,10 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
         if constexpr (!EDGE) {
             const uint32_t gr = pr[ky * G::RWC];
             uint32_t gr2 = gr;
-            if constexpr (WRAPW && DLO < 0) gr2 = pr2[ky * G::RWC];
+            if constexpr (WRAPW && (RIGHT ? DHI > 0 : DLO < 0)) gr2 = pr2[ky * G::RWC];
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = (float)cdist(pl[ky * LWC + dl], dl < 0 ? gr2 : gr);   // M.cpp:1490
+            for (int dl = DLO; dl <= DHI; dl++)
+                c[dl + 3] = (float)cdist(pl[ky * LWC + dl], (RIGHT ? dl > 0 : dl < 0) ? gr2 : gr);   // M.cpp:1490
         } else {
 #pragma unroll
             for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = (float)cdist(sL[ky * LWC + iL[dl + 3]], sR[ky * G::RWC + iR[dl + 3]]);
@@ -161,9 +167,9 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
         const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * G::NPOS);
         const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
         float wr2[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
-        if constexpr ((WRAPW || EDGE) && BHI >= 1) {
+        if constexpr ((WRAPW || EDGE) && (RIGHT ? BLO <= 2 : BHI >= 1)) {
             const float4 w2 = *reinterpret_cast<const float4*>(pwr2 + ky * G::NPOS);
-            wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
+            wr2[0] = w2.x; wr2[1] = w2.y; wr2[2] = w2.z; wr2[3] = w2.w;
         }
 #pragma unroll
         for (int b = BLO; b <= BHI; b++) {
@@ -177,7 +183,7 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
                 ab[0] = p0.x; ab[1] = p0.y; ab[2] = p1.x; ab[3] = p1.y;
             } else {
 #pragma unroll
-                for (int a = 0; a < 4; a++) ab[a] = wl[a] * (a < b ? wr2[b] : wr[b]);   // f32
+                for (int a = 0; a < 4; a++) ab[a] = wl[a] * ((RIGHT ? b < a : a < b) ? wr2[b] : wr[b]);   // f32
             }
 #pragma unroll
             for (int a = 0; a < 4; a++) {
@@ -193,7 +199,7 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
     }
 }
 
-template <int NWAVE, bool EDGE, bool WRAPW>
+template <int NWAVE, bool EDGE, bool WRAPW, bool RIGHT>
 __device__ __forceinline__ void run_all_steps(unsigned char* smem, const uint16_t* __restrict__ wLrow, const uint16_t* __restrict__ wRrow,
                                               size_t plane, int wave, int lane, int xl, int g, int qrel, int qrel2, int xabs, int dbase,
                                               int dbase2, int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
@@ -204,7 +210,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const uint16_
         if constexpr (EDGE) stage_weights<NWAVE>((KK) + 1, wLrow, wRrow, plane, smem, wave, lane, xl, posmin, W);    \
         else stage_issue<NWAVE>((KK) + 1, wLrow, wRrow, plane, wave, lane, xl, posmin, W, st);                       \
     }                                                                                                                \
-    run_step<NWAVE, (KK), EDGE, WRAPW, (!EDGE && (KK) + 1 < NSTEP)>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, \
+    run_step<NWAVE, (KK), EDGE, WRAPW, (!EDGE && (KK) + 1 < NSTEP), RIGHT>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, \
                                                                     den, wave, lane, st);                            \
     __syncthreads();
     ASW_GXQ_STEP(0) ASW_GXQ_STEP(1) ASW_GXQ_STEP(2) ASW_GXQ_STEP(3) ASW_GXQ_STEP(4) ASW_GXQ_STEP(5)
@@ -215,7 +221,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const uint16_
 
 // grid (tiles of this launch, H), 64 * NWAVE threads.  imgL / imgR: packed BGRX planes; wL / wR: u16 weight planes
 // [225][H][W].  vol (optional): [nD][H][W]; outE / outD: one slice [H][W] of per-pass winners (strict '<' in ascending d).
-template <int NWAVE, bool EDGE>
+template <int NWAVE, bool EDGE, bool RIGHT>
 __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_geodesic_xq(
     GeoXqParams p, const uint32_t* __restrict__ imgL, const uint32_t* __restrict__ imgR, const uint16_t* __restrict__ wL,
     const uint16_t* __restrict__ wR, float* __restrict__ vol, double* __restrict__ outE, float* __restrict__ outD)
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
     const int x0 = (p.tile0 + blockIdx.x) * PXW, y = blockIdx.y;
-    const int posmin = x0 - p.d0 - 4 * G::NJ;
+    const int posmin = RIGHT ? x0 + p.d0 : x0 - p.d0 - 4 * G::NJ;
     const size_t plane = (size_t)H * W;
 
     {   // BGRX tiles, replicate-clamped (M.cpp:1485-1486, 1490)
@@ -245,8 +251,8 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
     // lane -> (pixel group g, position block jl), as in k_bilateral_xq.hip
     const int g = (lane & 7) | ((lane >> 2) & 8);
     const int jl = 4 * wave + ((lane >> 3) & 3);
-    const int qrel = 4 * g + 4 * (G::NJ - jl);
-    const int qrel2 = jl == 0 ? 4 * g : qrel;               // block NJ's positions for the wrapped units (a < b) of block 0
+    const int qrel = RIGHT ? 4 * g + 4 * jl : 4 * g + 4 * (G::NJ - jl);
+    const int qrel2 = jl == 0 ? (RIGHT ? 4 * g + 4 * G::NJ : 4 * g) : qrel;  // block NJ's positions for the wrapped units of block 0
     const int xabs = x0 + 4 * g;
     const int dbase = p.d0 + 4 * jl;
     const int dbase2 = jl == 0 ? p.d0 + 4 * G::NJ : dbase;
@@ -263,9 +269,9 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
     stage_weights<NWAVE>(0, wLrow, wRrow, plane, smem, wave, lane, xl, posmin, W);
     __syncthreads();
     if (EDGE || wave == 0)
-        run_all_steps<NWAVE, EDGE, true>(smem, wLrow, wRrow, plane, wave, lane, xl, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);
+        run_all_steps<NWAVE, EDGE, true, RIGHT>(smem, wLrow, wRrow, plane, wave, lane, xl, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);
     else
-        run_all_steps<NWAVE, EDGE, false>(smem, wLrow, wRrow, plane, wave, lane, xl, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);
+        run_all_steps<NWAVE, EDGE, false, RIGHT>(smem, wLrow, wRrow, plane, wave, lane, xl, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, num, den);
 
     // ---- E = num / den (M.cpp:1496; 0/0 = NaN for windows flat in both images, App. B-9) -> LDS [candidate][pixel]
     double* sE = reinterpret_cast<double*>(smem);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int c = (a < b ? dbase2 : dbase) - p.d0 + a - b;  // in [0, NFIN)
+            const int c = RIGHT ? (b < a ? dbase2 : dbase) - p.d0 + b - a : (a < b ? dbase2 : dbase) - p.d0 + a - b;  // in [0, NFIN)
             sE[c * PXW + 4 * g + a] = num[a][b] / den[a][b];
         }
     __syncthreads();
@@ -308,20 +314,31 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
 
 template <int NWAVE>
 int launch_pass(hipStream_t s, hipStream_t s_border, const GeoXqParams& base, const uint32_t* imgL, const uint32_t* imgR,
-                const uint16_t* wL, const uint16_t* wR, float* vol, double* outE, float* outD)
+                const uint16_t* wL, const uint16_t* wR, float* vol, double* outE, float* outD, bool right)
 {
     const int W = base.W, H = base.H;
     const int ntiles = (W + PXW - 1) / PXW;
+    if (right) {  // border tile = the first of a row
+        GeoXqParams p = base;
+        p.tile0 = 0;
+        hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, true, true>), dim3(1, H), dim3(64 * NWAVE), 0, s_border, p, imgL, imgR, wL, wR, vol, outE, outD);
+        if (ntiles > 1) {
+            p.tile0 = 1;
+            hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, false, true>), dim3(ntiles - 1, H), dim3(64 * NWAVE), 0, s, p, imgL, imgR, wL, wR, vol, outE, outD);
+        }
+        ASW_HIP_TRY(hipGetLastError());
+        return ASW_OK;
+    }
     const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;  // x0 + 63 + 7 <= W - 1
     if (n_int > 0) {
         GeoXqParams p = base;
         p.tile0 = 0;
-        hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, false>), dim3(n_int, H), dim3(64 * NWAVE), 0, s, p, imgL, imgR, wL, wR, vol, outE, outD);
+        hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, false, false>), dim3(n_int, H), dim3(64 * NWAVE), 0, s, p, imgL, imgR, wL, wR, vol, outE, outD);
     }
     if (ntiles > n_int) {
         GeoXqParams p = base;
         p.tile0 = n_int;
-        hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, true>), dim3(ntiles - n_int, H), dim3(64 * NWAVE), 0, s_border, p, imgL, imgR, wL, wR, vol, outE, outD);
+        hipLaunchKernelGGL((k_asw_geodesic_xq<NWAVE, true, false>), dim3(ntiles - n_int, H), dim3(64 * NWAVE), 0, s_border, p, imgL, imgR, wL, wR, vol, outE, outD);
     }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
@@ -332,12 +349,13 @@ int launch_pass(hipStream_t s, hipStream_t s_border, const GeoXqParams& base, co
 // Candidates a pass of `nwave` wavefronts finishes (nwave = 8 or 4).
 int geodesic_xq_pass_candidates(int nwave) { return 16 * nwave; }
 
-// One pass: candidates [cbase, cbase + 16 * nwave) of a DISPARITY_LEFT, win = 15 problem; winners -> outE / outD ([H][W]).
+// One pass: candidates [cbase, cbase + 16 * nwave) of a win = 15 problem; winners -> outE / outD ([H][W]).
+// right: DISPARITY_RIGHT -- imgL / wL are then the fixed (right) image's planes, imgR / wR the left image's.
 int launch_geodesic_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,
-                       const uint16_t* wR, int H, int W, int minD, int cbase, float* vol, double* outE, float* outD)
+                       const uint16_t* wR, int H, int W, int minD, int cbase, float* vol, double* outE, float* outD, bool right)
 {
     GeoXqParams p{H, W, minD + cbase, cbase, 0};
-    if (nwave == 8) return launch_pass<8>(s, s_border, p, imgL, imgR, wL, wR, vol, outE, outD);
-    if (nwave == 4) return launch_pass<4>(s, s_border, p, imgL, imgR, wL, wR, vol, outE, outD);
+    if (nwave == 8) return launch_pass<8>(s, s_border, p, imgL, imgR, wL, wR, vol, outE, outD, right);
+    if (nwave == 4) return launch_pass<4>(s, s_border, p, imgL, imgR, wL, wR, vol, outE, outD, right);
     return ASW_ERR_BAD_ARGUMENT;
 }

@@ -1,6 +1,6 @@
 """The xq form of the classic bilateral kernel (k_bilateral_xq.hip: thread = 4 pixels x 4 right-image positions, candidates
-[0, 125) + a tail launch of k_asw_bilateral) against the oracle and against the one-kernel path, bit for bit.  It serves
-DISPARITY_LEFT, win = 15, numDisparity >= 127 (the reference's configuration at 1080p, M.cpp:58 / main.cpp:94)."""
+[0, 128) + a tail launch of k_asw_bilateral) against the oracle and against the one-kernel path, bit for bit.  It serves
+both directions at win = 15, numDisparity >= 127 (the reference's configuration at 1080p, M.cpp:58 / main.cpp:94)."""
 import os
 
 import numpy as np
@@ -47,6 +47,31 @@ def test_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD):
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
+# DISPARITY_RIGHT (M.cpp:1113-1142): positions run to the right, the border tile is the first of a row; minD > 0 only while the
+# last tile still holds columns W-8..W-1 (x0_last + minD <= W - 1), else the one-kernel path serves the call
+RIGHT_SHAPES = [(5, 64, 0, 128), (9, 200, 0, 128), (3, 257, 0, 128), (17, 130, 1, 127), (4, 333, 12, 131), (2, 71, 6, 160),
+                (21, 96, 7, 128), (1, 640, 0, 128), (3, 200, 40, 128)]
+
+
+@pytest.mark.parametrize("H,W,minD,numD", RIGHT_SHAPES)
+def test_xq_right_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD):
+    L, R, _ = make_pair(H, W, min(numD, W // 2), seed=H * 1000 + W + 7, block=16)
+    d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, minD, numD, return_cost_volume=True)
+    rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 1, 15, minD, numD, want_vol=True)
+    assert rc == 0 and v.shape == vw.shape == (numD + 1, H, W)
+    assert np.array_equal(v, vw, equal_nan=True), np.argwhere(v != vw)[:5]
+    assert np.array_equal(d, dw)
+    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, minD, numD, return_cost_volume=True))
+    assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
+
+
+def test_xq_right_mid_size_and_lr_check(ctx):
+    L, R, _ = make_pair(135, 480, 128, seed=15)
+    d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
+    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True))
+    assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
+
+
 def test_xq_flat_and_random_images(ctx, oracle):
     # constant images: all costs 0, every E = 0 -> d = minD everywhere; pure noise: ties and large gray steps
     for L, R in ((np.full((6, 150, 3), 80, np.uint8), np.full((6, 150, 3), 80, np.uint8)),
@@ -70,9 +95,9 @@ def test_xq_other_gammas_and_selector(ctx, oracle):
     assert np.array_equal(ctx.download_disparity(5, (7, 180)), oracle.asw_classic(L, R, 30, 20, 0, 15, 0, 128)[1])
 
 
-def test_right_and_other_windows_stay_on_the_one_kernel_path(ctx, oracle):
+def test_other_windows_stay_on_the_one_kernel_path(ctx, oracle):
     L, R, _ = make_pair(6, 140, 40, seed=13, block=16)
-    for dt, win in ((RIGHT, 15), (LEFT, 13), (LEFT, 17)):
+    for dt, win in ((RIGHT, 13), (LEFT, 13), (LEFT, 17)):
         d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, win, 0, 128, return_cost_volume=True)
         rc, dw, vw = oracle.asw_classic(L, R, 30, 20, int(dt), win, 0, 128, want_vol=True)
         assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw), (dt, win)

@@ -34,18 +34,19 @@ SHAPES = [(4, 64, 0, 63), (6, 150, 0, 70), (3, 200, 0, 127), (5, 257, 0, 192), (
           (7, 71, 0, 140)]
 
 
+@pytest.mark.parametrize("dt", [LEFT, RIGHT])   # M.cpp:1467-1496 / 1498-1520
 @pytest.mark.parametrize("H,W,minD,numD", SHAPES)
-def test_geodesic_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD):
+def test_geodesic_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD, dt):
     L, R, _ = make_pair(H, W, min(numD, W // 2), seed=H * 977 + W, block=16)
     if H > 2:
         L[1:3, 20:40] = L[1, 20]   # flat patches: zero weights, 0/0 = NaN slots (App. B-9)
         R[1:3, 10:34] = R[1, 10]
-    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, 15, minD, numD, return_cost_volume=True)
-    rc, dw, vw = oracle.asw_geodesic(L, R, 0, 15, minD, numD, want_vol=True)
+    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, minD, numD, return_cost_volume=True)
+    rc, dw, vw = oracle.asw_geodesic(L, R, int(dt), 15, minD, numD, want_vol=True)
     assert rc == 0 and v.shape == vw.shape == (numD + 1, H, W)
     assert np.array_equal(v, vw, equal_nan=True), np.argwhere(~((v == vw) | (np.isnan(v) & np.isnan(vw))))[:5]
     assert np.array_equal(d, dw)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, 15, minD, numD, return_cost_volume=True))
+    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, minD, numD, return_cost_volume=True))
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
@@ -55,14 +56,15 @@ def test_geodesic_xq_selector_resident_and_other_cases(ctx, oracle):
     ctx.upload_pair(6, L, R)
     ctx.match_resident(6, LEFT, A.ADAPTIVE_WEIGHT_GEODESIC, 15, 0, 192, keep_volume=False)
     assert np.array_equal(ctx.download_disparity(6, (6, 180)), oracle.asw_geodesic(L, R, 0, 15, 0, 192)[1])
-    for dt, win in ((RIGHT, 15), (LEFT, 13), (LEFT, 17)):   # stay on the one-kernel path
+    for dt, win in ((RIGHT, 13), (LEFT, 13), (LEFT, 17)):   # stay on the one-kernel path
         d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, win, 0, 100, return_cost_volume=True)
         rc, dw, vw = oracle.asw_geodesic(L, R, int(dt), win, 0, 100, want_vol=True)
         assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw), (dt, win)
 
 
-def test_geodesic_xq_mid_size_equals_one_kernel_path(ctx):
+@pytest.mark.parametrize("dt", [LEFT, RIGHT])
+def test_geodesic_xq_mid_size_equals_one_kernel_path(ctx, dt):
     L, R, _ = make_pair(188, 621, 192, seed=32)
-    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, 15, 0, 192, return_cost_volume=True)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, LEFT, 15, 0, 192, return_cost_volume=True))
+    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, 0, 192, return_cost_volume=True)
+    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, 0, 192, return_cost_volume=True))
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)

@@ -36,11 +36,11 @@ def main():
     ap.add_argument("--flat", type=float, default=0.25, help="share of the cases whose images get constant rectangles (flat windows: 0/0 NCC costs, zero variances, ties)")
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
-                    "DISPARITY_LEFT, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
+                    "both directions, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = asw.Context(0)
-    O.set_threads(min(16, O.max_threads()))
+    O.set_threads(O.usable_cores())
     t0 = time.time()
     n = fails = 0
     counts = {}
@@ -75,7 +75,7 @@ def main():
         if rng.random() < args.xq:
             method = str(rng.choice(["classic", "geodesic"]))
             H, W = int(rng.integers(1, 10)), int(rng.integers(64, 420))
-            win, dt = 15, 0
+            win, dt = 15, int(rng.integers(0, 2))   # both directions have an xq form
             minD = int(rng.choice([0, 0, 1, 5, 48, 49, 70])) if method == "classic" else int(rng.choice([0, 0, 2, 33, 130]))
             numD = int(rng.choice([63, 64, 127, 128, 129, 191, 192, 255, int(rng.integers(63, 300))]))
             seed = int(rng.integers(0, 1 << 30))

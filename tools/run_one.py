@@ -15,11 +15,12 @@ ap.add_argument("--disp", type=int, default=128)
 ap.add_argument("--win", type=int, default=15)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--keep-volume", type=int, default=1)
+ap.add_argument("--disparity-type", type=int, default=0, help="0 = DISPARITY_LEFT, 1 = DISPARITY_RIGHT")
 a = ap.parse_args()
 L, R, _ = make_pair(a.height, a.width, a.disp, seed=1234)
 ctx = asw.Context(0)
 ctx.upload_pair(0, L, R)
 for i in range(a.reps):
-    ctx.match_resident(0, 0, a.alg, a.win, 0, a.disp, keep_volume=bool(a.keep_volume))
+    ctx.match_resident(0, a.disparity_type, a.alg, a.win, 0, a.disp, keep_volume=bool(a.keep_volume))
     print(i, ctx.timing(), flush=True)
 ctx.close()
