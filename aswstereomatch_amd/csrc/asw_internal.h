@@ -199,6 +199,9 @@ int launch_wm_weights(hipStream_t s, const uint8_t* img, int H, int W, int pad, 
                       float* out);
 int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
                    int max_off, float* out);
+size_t wmedian_tile_list_slots(int H, int W, int d_count);
+int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int numD, int max_off,
+                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out);
 
 // ---- O(1)-bilateral ASW (BLO1), k_blo1.hip ----
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,

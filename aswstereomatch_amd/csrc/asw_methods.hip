@@ -542,8 +542,23 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_wm_weights(ctx->stream, dL, H, W, 0, mp.win, ctx->wm_lut2.as<float>(), ctx->wm_wd.as<float>(), wl.as<float>()));
     ASW_TRY(launch_wm_weights(ctx->stream, dR, H, W, max_off, mp.win, ctx->wm_lut2.as<float>(), nullptr, wr.as<float>()));
-    ASW_TRY(launch_wmedian(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off,
-                           f->vol.as<float>()));
+    // 15x15 (the reference's call site): the neighbourhood of an 8x8 pixel block is sorted once per slice and every pixel walks
+    // it (k_wmedian_tile.hip); other windows sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
+    // (3 KB per block and slice) below 2 GiB.  ASW_WMEDIAN_TILE=0 forces the per-pixel sort (A/B measurements, tests).
+    const char* wmt_env = getenv("ASW_WMEDIAN_TILE");
+    if (mp.win == 15 && !(wmt_env && wmt_env[0] == '0')) {
+        const size_t per_slice = wmedian_tile_list_slots(H, W, 1);
+        int chunk = (int)std::min<size_t>((size_t)n, std::max<size_t>(8, (((size_t)2 << 30) / 6 / per_slice) / 8 * 8));
+        DevBuf& lc = ctx->buf("wmListC");
+        DevBuf& lp = ctx->buf("wmListP");
+        ASW_TRY(lc.ensure(per_slice * chunk * 4));
+        ASW_TRY(lp.ensure(per_slice * chunk * 2));
+        for (int d0 = 0; d0 < n; d0 += chunk)
+            ASW_TRY(launch_wmedian_tile(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, n, max_off, d0,
+                                        std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>()));
+    } else
+        ASW_TRY(launch_wmedian(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off,
+                               f->vol.as<float>()));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3365-3381
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->timing.aggregate_launches = 4;

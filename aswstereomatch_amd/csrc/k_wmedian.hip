@@ -18,6 +18,7 @@
 // exp() values come from host-built tables (same libm as the oracle), so weights are bit-identical.
 #include "asw_device.h"
 #include "asw_internal.h"
+#include "wm_network.h"
 
 namespace {
 
@@ -54,101 +55,7 @@ __global__ __launch_bounds__(256) void k_wm_weights(const uint8_t* __restrict__ 
 // compare-exchange, no 64-bit compares.
 constexpr uint32_t COST_BASE_BITS = 0x45800000u;  // 4096.0f
 
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-
-// value of lane (lane ^ LM)
-template <int LM>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
-{
-    if constexpr (LM == 1) return dpp_mov<0xB1>(v);         // quad_perm [1,0,3,2]
-    else if constexpr (LM == 2) return dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    else if constexpr (LM == 3) return dpp_mov<0x1B>(v);    // quad_perm [3,2,1,0]
-    else if constexpr (LM == 7) return dpp_mov<0x141>(v);   // row_half_mirror
-    else if constexpr (LM == 15) return dpp_mov<0x140>(v);  // row_mirror
-    else if constexpr (LM == 8) return dpp_mov<0x128>(v);   // row_ror:8 == xor 8 inside a 16-lane row
-    else if constexpr (LM == 4 || LM == 16 || LM == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (LM << 10) | 0x1f);
-    else return (uint32_t)__shfl_xor((int)v, LM);
-}
-
-// Sorting network: merges of size K = 2, 4, ..., 256 over element e = lane*4 + r.  Every merge starts with a
-// MIRROR step (partner e ^ (K-1)) and continues with half-cleaners (partner e ^ j): all comparisons then sort
-// ascending -- the lower index takes the minimum -- so intra-lane exchanges are a bare v_min/v_max pair and
-// cross-lane ones select with one of six loop-invariant lane masks (bit 0..5 of the lane id).
-struct LaneMasks { uint32_t m[6]; };  // m[b] = all ones where bit b of the lane id is clear (loop-invariant VGPRs)
-
-template <int LM>
-__device__ __forceinline__ unsigned long long lane_xor(unsigned long long v)
-{
-    const uint32_t lo = lane_xor<LM>((uint32_t)v), hi = lane_xor<LM>((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// The network is written for KPL keys per lane (element e = lane*KPL + r) of type T (u32: the 256-slot fast path;
-// u64: the general path for windows above 15x15).
-template <int LM, int RX, int BITLOG, class T, int KPL>  // partner = (lane ^ LM, r ^ RX); the lane with bit BITLOG clear is the lower one
-__device__ __forceinline__ void cross_step(T (&key)[KPL], const LaneMasks& lm)
-{
-    const bool lower = lm.m[BITLOG] != 0u;
-    T o[KPL];
-#pragma unroll
-    for (int r = 0; r < KPL; r++) o[r] = lane_xor<LM>(key[r ^ RX]);
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const T mn = min(key[r], o[r]), mx = max(key[r], o[r]);
-        key[r] = lower ? mn : mx;  // lower lane keeps the minimum, upper lane the maximum
-    }
-}
-
-template <int RX, class T, int KPL>  // intra-lane: pairs (r, r ^ RX)
-__device__ __forceinline__ void local_step(T (&key)[KPL])
-{
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const int q = r ^ RX;
-        if (q > r) {
-            const T a = key[r], b = key[q];
-            key[r] = min(a, b);
-            key[q] = max(a, b);
-        }
-    }
-}
-
-constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
-
-template <int J, class T, int KPL>  // half-cleaner steps j = J, J/2, ..., 1 (element distance)
-__device__ __forceinline__ void half_cleaners(T (&key)[KPL], const LaneMasks& lm)
-{
-    if constexpr (J >= KPL) {
-        cross_step<J / KPL, 0, ilog2(J / KPL)>(key, lm);
-        half_cleaners<J / 2>(key, lm);
-    } else if constexpr (J >= 1) {
-        local_step<J>(key);
-        if constexpr (J > 1) half_cleaners<J / 2>(key, lm);
-    }
-}
-
-template <int K, class T, int KPL>
-__device__ __forceinline__ void merge_sorted_halves(T (&key)[KPL], const LaneMasks& lm)
-{
-    if constexpr (K <= KPL) {
-        local_step<K - 1>(key);  // mirror inside the lane: (r, r ^ (K-1))
-        if constexpr (K > 2) half_cleaners<K / 4>(key, lm);
-    } else {
-        cross_step<K / KPL - 1, KPL - 1, ilog2(K / (2 * KPL))>(key, lm);  // mirror: lane ^ (K/KPL-1), register ^ (KPL-1)
-        half_cleaners<K / 4>(key, lm);
-    }
-}
-
-template <int K, class T, int KPL>
-__device__ __forceinline__ void bitonic_sort(T (&key)[KPL], const LaneMasks& lm)
-{
-    if constexpr (K > 2) bitonic_sort<K / 2>(key, lm);
-    merge_sorted_halves<K>(key, lm);
-}
+using namespace wmnet;
 
 constexpr int WM_WAVES = 4;
 

@@ -1,0 +1,245 @@
+// Weighted-median aggregation for the 15x15 window (computeAdaptiveWeight_WeightedMedian, M.cpp:3228-3308), second form:
+// "sort the neighbourhood once, let every pixel walk it".
+//
+// k_wmedian.hip sorts the 225 (cost, weight) pairs of every (pixel, d) from scratch: ~190 of its ~370 instructions per pair
+// are the 36-step network.  But the costs of slice d are ONE plane shared by all pixels; only the weights are per pixel.
+// For an 8x8 block of pixels the union of the windows is a 22x22 region of that plane (484 samples), and the multimap order
+// of any window in it -- ascending cost, ties in row-major window order (M.cpp:3276-3283) -- is the order of the region
+// sorted by (cost, row-major region index) restricted to the window's members: a translation keeps row-major order.  So
+//   1. k_wm_sort_regions: one wavefront sorts the region of a (block, d) once (512 slots, 8 per lane, f64 keys
+//      = cost bits * 1024 + region index: exact integers, compare-exchange = v_min_f64 / v_max_f64) -> list in memory;
+//   2. k_wm_pick: a wavefront takes the list of a (block, d) (8 entries per lane, in sorted order) and, for each of the 64
+//      pixels, turns every entry into (member of this pixel's window ? weight : 0) -- a byte table maps the entry's
+//      position relative to the pixel to the window cell or to a zero slot, the weights wL*wd (per pixel, in LDS for the
+//      whole block) and wR (row of 225, staged per pixel) are gathered by cell -- then forms the f64 prefix sums in sorted
+//      order (8 per lane + a DPP wavefront scan), finds the first prefix above half of the total (M.cpp:3284-3291) and
+//      returns the cost of the last member before it (or of the crossing element itself if it is the first, :3293-3301).
+// No per-pixel sort: ~9 instructions per list entry and pixel instead of a 36-step network per pixel.
+// The arithmetic is that of k_wmedian.hip (f32 weight product in the reference's order, f64 sums; the association of the
+// prefix sums differs from the reference's sequential walk in the last bits only, as there).
+#include "asw_device.h"
+#include "asw_internal.h"
+#include "wm_network.h"
+
+namespace {
+using namespace wmnet;
+
+constexpr int WIN = 15, HW = 7, NC = WIN * WIN;   // 225 window cells
+constexpr int BW = 8, BH = 8, NPIX = BW * BH;     // pixel block
+constexpr int RW = BW + 2 * HW, RH = BH + 2 * HW; // 22 x 22 region
+constexpr int NREG = RW * RH;                     // 484 samples
+constexpr int SLOTS = 512, KPL = 8;
+constexpr uint32_t COST_BASE_BITS = 0x45800000u;  // 4096.0f: every TAD C+G cost lies in [4096, 16384) (k_wmedian.hip)
+constexpr uint32_t POS_PAD = 1023u;               // position of the 28 padding slots: never inside a window
+constexpr double KEY_PAD = 4398046511104.0;       // 2^42: above every real key (cost bits < 2^24, * 1024)
+constexpr int WLS = NC + 1;                       // per-pixel weight row + the zero slot (cell 225 = "not in this window")
+constexpr int WRS = 228;                          // staged right row + zero slot, padded
+constexpr int NT = 481;                           // relative position -> cell table: 15 rows x 32 + the clamp slot
+constexpr int PICK_WAVES = 8;
+
+// ---- 1. sort the 22 x 22 cost region of every (block, d) --------------------------------------------------------------------
+// grid (blocks, ceil(d_count / 4)), 256 threads: wavefront w sorts slice d_begin + 4 * blockIdx.y + w.
+// listC / listP: [block][d_count][512] sorted cost bits / positions (row << 5 | column inside the region).
+__global__ __launch_bounds__(256) void k_wm_sort_regions(const float* __restrict__ cost /* [numD][H][W] */, int H, int W, int nbx,
+                                                         int d_begin, int d_count, uint32_t* __restrict__ listC,
+                                                         uint16_t* __restrict__ listP)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dd = blockIdx.y * 4 + wv;
+    if (dd >= d_count) return;  // whole wavefront
+    const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
+    const int x0 = bx * BW, y0 = by * BH;
+    const float* cp = cost + (size_t)(d_begin + dd) * H * W;
+    LaneMasks lm;
+#pragma unroll
+    for (int b = 0; b < 6; b++) lm.m[b] = (lane & (1 << b)) ? 0u : 0xffffffffu;
+    double key[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = lane * KPL + r;
+        if (e < NREG) {
+            const int ey = e / RW, ex = e - ey * RW;
+            // the window's sample at the REFLECT-padded position (M.cpp:665, 3273)
+            const float c = cp[(size_t)reflect_idx(y0 - HW + ey, H) * W + reflect_idx(x0 - HW + ex, W)];
+            key[r] = (double)(__float_as_uint(c) - COST_BASE_BITS) * 1024.0 + (double)(ey * 32 + ex);
+        } else {
+            key[r] = KEY_PAD + (double)e;
+        }
+    }
+    bitonic_sort<SLOTS>(key, lm);
+    uint32_t oc[KPL], op[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const bool pad = key[r] >= KEY_PAD;
+        const uint32_t c24 = (uint32_t)(key[r] * (1.0 / 1024.0));             // exact: division by a power of two, truncation
+        const uint32_t pos = (uint32_t)(key[r] - (double)c24 * 1024.0);
+        oc[r] = pad ? 0u : c24 + COST_BASE_BITS;
+        op[r] = pad ? POS_PAD : pos;
+    }
+    const size_t base = ((size_t)blk * d_count + dd) * SLOTS + (size_t)lane * KPL;
+    uint4* pc = reinterpret_cast<uint4*>(listC + base);
+    pc[0] = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+    pc[1] = make_uint4(oc[4], oc[5], oc[6], oc[7]);
+    *reinterpret_cast<uint4*>(listP + base) = make_uint4(op[0] | (op[1] << 16), op[2] | (op[3] << 16), op[4] | (op[5] << 16), op[6] | (op[7] << 16));
+}
+
+// ---- 2. every pixel of the block walks the sorted region -------------------------------------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v)  // lanes without a source (row edge, masked rows) read 0
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, ROWMASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+
+__device__ __forceinline__ double wave_inclusive_scan(double v)
+{
+    v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> inclusive inside each row of 16
+    v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// grid (blocks), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, all 64 pixels of the block.
+__global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __restrict__ wLd /* [H][W][225] */,
+                                                             const float* __restrict__ wRb /* [H][Wb][225] */,
+                                                             const uint32_t* __restrict__ listC, const uint16_t* __restrict__ listP,
+                                                             int H, int W, int nbx, int numD, int max_off, int d_begin, int d_count,
+                                                             float* __restrict__ out /* [numD][H][W] */)
+{
+    __shared__ float sWL[NPIX * WLS];         // 57 856 B: (wL .mul wd) of the block's pixels, slot 225 = 0
+    __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: wR row of the pixel a wavefront is working on, slot 225 = 0
+    __shared__ uint8_t sT[NT + 3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
+    const int x0 = bx * BW, y0 = by * BH;
+    const int Wb = W + max_off;
+    const size_t plane = (size_t)H * W;
+
+    for (int i = tid; i < NPIX * WLS; i += 64 * PICK_WAVES) {
+        const int p = i / WLS, c = i - p * WLS;
+        const int x = x0 + (p & 7), y = y0 + (p >> 3);
+        sWL[i] = (c < NC && x < W && y < H) ? wLd[((size_t)y * W + x) * NC + c] : 0.0f;
+    }
+    for (int i = tid; i < NT; i += 64 * PICK_WAVES) {  // t = dy * 32 + dx + 7 (dx, dy relative to the window's first cell)
+        const int dy = i >> 5, dx = (i & 31) - HW;
+        sT[i] = (uint8_t)((i < NT - 1 && dy < WIN && dx >= 0 && dx < WIN) ? dy * WIN + dx : NC);
+    }
+    if (lane < WRS - NC) sWR[wv][NC + lane] = 0.0f;
+    __syncthreads();
+
+    float* wrp = sWR[wv];
+    for (int dd = wv; dd < d_count; dd += PICK_WAVES) {
+        const int d = d_begin + dd;
+        const size_t lbase = ((size_t)blk * d_count + dd) * SLOTS + (size_t)lane * KPL;
+        const uint4 c0 = reinterpret_cast<const uint4*>(listC + lbase)[0], c1 = reinterpret_cast<const uint4*>(listC + lbase)[1];
+        const uint4 pp = *reinterpret_cast<const uint4*>(listP + lbase);
+        const uint32_t cst[KPL] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const int pos[KPL] = {(int)(pp.x & 0xffffu), (int)(pp.x >> 16), (int)(pp.y & 0xffffu), (int)(pp.y >> 16),
+                              (int)(pp.z & 0xffffu), (int)(pp.z >> 16), (int)(pp.w & 0xffffu), (int)(pp.w >> 16)};
+        float* od = out + (size_t)d * plane;
+
+        // right-image weight row of pixel p at this d: weightWinsR[y][x - offset + numDisparity - 1] (M.cpp:3274)
+        float nxt[4];
+        auto fetch = [&](int p) {
+            const int x = x0 + (p & 7), y = y0 + (p >> 3);
+            const float* row = wRb + ((size_t)y * Wb + (x - d + numD - 1)) * NC;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = lane + 64 * k;
+                nxt[k] = c < NC ? row[c] : 0.0f;
+            }
+        };
+        auto valid = [&](int p) { return x0 + (p & 7) < W && y0 + (p >> 3) < H; };
+        fetch(0);  // pixel 0 of a block always exists
+        for (int p = 0; p < NPIX; p++) {
+            if (!valid(p)) continue;  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (lane + 64 * k < NC) wrp[lane + 64 * k] = nxt[k];
+            int pn = p + 1;
+            while (pn < NPIX && !valid(pn)) pn++;
+            if (pn < NPIX) fetch(pn);  // in flight under this pixel's arithmetic
+            __builtin_amdgcn_wave_barrier();
+
+            const float* wlp = sWL + p * WLS;
+            const int base7 = (p >> 3) * 32 + (p & 7) - HW;
+            double run = 0.0, pre[KPL];
+            uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit 7 - r
+#pragma unroll
+            for (int r = 0; r < KPL; r++) {
+                const uint32_t t = min((uint32_t)(pos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
+                const int cell = sT[t];
+                const float w = wlp[cell] * wrp[cell];  // (wL .mul wd) .mul wR in f32 (M.cpp:3274); 0 outside the window
+                run += (double)w;
+                pre[r] = run;
+                mb = (mb << 1) | (cell != NC ? 1u : 0u);
+            }
+            const double incl = wave_inclusive_scan(run);
+            const double half = readlane_f64(incl, 63) * 0.5;  // cv::sum(weight_img_win)[0] / 2, M.cpp:3284
+            const double excl = incl - run;
+            int first = KPL;
+#pragma unroll
+            for (int r = KPL - 1; r >= 0; r--)
+                if (excl + pre[r] > half) first = r;
+            const unsigned long long ball = __ballot(first < KPL);
+            float res = 0.0f;
+            if (ball) {  // wave-uniform
+                const int fl = __ffsll((long long)ball) - 1;
+                const int fr = __builtin_amdgcn_readlane(first, fl);
+                const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)mb, fl);
+                const uint32_t before = bits >> (8 - fr);  // members among entries 0 .. fr-1 of that lane, entry fr-1 at bit 0
+                int pl = fl, pr = fr;  // the crossing element itself if nothing precedes it (M.cpp:3293-3296)
+                if (before) {
+                    pr = fr - 1 - __builtin_ctz(before);
+                } else {
+                    const unsigned long long lower = __ballot(mb != 0u) & ((1ull << fl) - 1ull);
+                    if (lower) {
+                        pl = 63 - __builtin_clzll(lower);
+                        pr = 7 - __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)mb, pl));  // its last member
+                    }
+                }
+                uint32_t sel = cst[0];
+#pragma unroll
+                for (int q = 1; q < KPL; q++) sel = pr == q ? cst[q] : sel;
+                res = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sel, pl));
+            }
+            if (lane == 0) od[(size_t)(y0 + (p >> 3)) * W + x0 + (p & 7)] = res;
+        }
+    }
+}
+
+}  // namespace
+
+// Scratch for `d_count` slices handled by one pair of launches: sorted cost bits (u32) and positions (u16) of every block.
+size_t wmedian_tile_list_slots(int H, int W, int d_count)
+{
+    const size_t nb = (size_t)((W + BW - 1) / BW) * ((H + BH - 1) / BH);
+    return nb * (size_t)d_count * SLOTS;
+}
+
+// Slices [d_begin, d_begin + d_count) of the 15x15 weighted median; listC: u32[slots], listP: u16[slots].
+int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int numD, int max_off,
+                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out)
+{
+    if (d_count <= 0 || d_begin < 0 || d_begin + d_count > numD) return ASW_ERR_BAD_ARGUMENT;
+    const int nbx = (W + BW - 1) / BW, nby = (H + BH - 1) / BH;
+    hipLaunchKernelGGL(k_wm_sort_regions, dim3((unsigned)(nbx * nby), (unsigned)((d_count + 3) / 4)), dim3(256), 0, s, cost, H, W, nbx,
+                       d_begin, d_count, listC, listP);
+    hipLaunchKernelGGL(k_wm_pick, dim3((unsigned)(nbx * nby)), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx, numD,
+                       max_off, d_begin, d_count, out);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
