@@ -549,6 +549,7 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     if (mp.win == 15 && !(wmt_env && wmt_env[0] == '0')) {
         const size_t per_slice = wmedian_tile_list_slots(H, W, 1);
         int chunk = (int)std::min<size_t>((size_t)n, std::max<size_t>(8, (((size_t)2 << 30) / 6 / per_slice) / 8 * 8));
+        if (const char* ce = getenv("ASW_WMEDIAN_TILE_CHUNK")) chunk = std::max(1, std::min(n, atoi(ce)));  // tests: odd chunkings
         DevBuf& lc = ctx->buf("wmListC");
         DevBuf& lp = ctx->buf("wmListP");
         ASW_TRY(lc.ensure(per_slice * chunk * 4));

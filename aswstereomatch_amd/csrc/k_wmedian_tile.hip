@@ -17,6 +17,8 @@
 // No per-pixel sort: ~9 instructions per list entry and pixel instead of a 36-step network per pixel.
 // The arithmetic is that of k_wmedian.hip (f32 weight product in the reference's order, f64 sums; the association of the
 // prefix sums differs from the reference's sequential walk in the last bits only, as there).
+#include <stdlib.h>
+
 #include "asw_device.h"
 #include "asw_internal.h"
 #include "wm_network.h"
@@ -112,30 +114,35 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// grid (blocks), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, all 64 pixels of the block.
+// grid (blocks, NSPLIT), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, the 64 / NSPLIT pixels
+// (whole rows of the block) of this workgroup's part.  NSPLIT = 2 halves the LDS weight slab: four workgroups per CU.
+template <int NSPLIT>
 __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __restrict__ wLd /* [H][W][225] */,
                                                              const float* __restrict__ wRb /* [H][Wb][225] */,
                                                              const uint32_t* __restrict__ listC, const uint16_t* __restrict__ listP,
                                                              int H, int W, int nbx, int numD, int max_off, int d_begin, int d_count,
                                                              float* __restrict__ out /* [numD][H][W] */)
 {
-    __shared__ float sWL[NPIX * WLS];         // 57 856 B: (wL .mul wd) of the block's pixels, slot 225 = 0
+    constexpr int NPART = NPIX / NSPLIT;
+    __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels, slot 225 = 0
     __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: wR row of the pixel a wavefront is working on, slot 225 = 0
-    __shared__ uint8_t sT[NT + 3];
+    __shared__ uint16_t sT[NT + 1];           // relative position -> byte offset of the cell in a weight row (900 = zero slot)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
     const int x0 = bx * BW, y0 = by * BH;
     const int Wb = W + max_off;
     const size_t plane = (size_t)H * W;
 
-    for (int i = tid; i < NPIX * WLS; i += 64 * PICK_WAVES) {
-        const int p = i / WLS, c = i - p * WLS;
+    const int p_begin = blockIdx.y * NPART;
+    if (y0 + (p_begin >> 3) >= H) return;  // this part lies below the image (whole workgroup)
+    for (int i = tid; i < NPART * WLS; i += 64 * PICK_WAVES) {
+        const int p = p_begin + i / WLS, c = i % WLS;
         const int x = x0 + (p & 7), y = y0 + (p >> 3);
         sWL[i] = (c < NC && x < W && y < H) ? wLd[((size_t)y * W + x) * NC + c] : 0.0f;
     }
     for (int i = tid; i < NT; i += 64 * PICK_WAVES) {  // t = dy * 32 + dx + 7 (dx, dy relative to the window's first cell)
         const int dy = i >> 5, dx = (i & 31) - HW;
-        sT[i] = (uint8_t)((i < NT - 1 && dy < WIN && dx >= 0 && dx < WIN) ? dy * WIN + dx : NC);
+        sT[i] = (uint16_t)(4 * ((i < NT - 1 && dy < WIN && dx >= 0 && dx < WIN) ? dy * WIN + dx : NC));
     }
     if (lane < WRS - NC) sWR[wv][NC + lane] = 0.0f;
     __syncthreads();
@@ -163,29 +170,31 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             }
         };
         auto valid = [&](int p) { return x0 + (p & 7) < W && y0 + (p >> 3) < H; };
-        fetch(0);  // pixel 0 of a block always exists
-        for (int p = 0; p < NPIX; p++) {
+        fetch(p_begin);  // the first pixel of a part always exists
+        for (int p = p_begin; p < p_begin + NPART; p++) {
             if (!valid(p)) continue;  // wave-uniform
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (lane + 64 * k < NC) wrp[lane + 64 * k] = nxt[k];
             int pn = p + 1;
-            while (pn < NPIX && !valid(pn)) pn++;
-            if (pn < NPIX) fetch(pn);  // in flight under this pixel's arithmetic
+            while (pn < p_begin + NPART && !valid(pn)) pn++;
+            if (pn < p_begin + NPART) fetch(pn);  // in flight under this pixel's arithmetic
             __builtin_amdgcn_wave_barrier();
 
-            const float* wlp = sWL + p * WLS;
+            const char* wlp = reinterpret_cast<const char*>(sWL + (p - p_begin) * WLS);
+            const char* wrq = reinterpret_cast<const char*>(wrp);
             const int base7 = (p >> 3) * 32 + (p & 7) - HW;
             double run = 0.0, pre[KPL];
             uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit 7 - r
 #pragma unroll
             for (int r = 0; r < KPL; r++) {
                 const uint32_t t = min((uint32_t)(pos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
-                const int cell = sT[t];
-                const float w = wlp[cell] * wrp[cell];  // (wL .mul wd) .mul wR in f32 (M.cpp:3274); 0 outside the window
-                run += (double)w;
+                const uint32_t c4 = sT[t];
+                // (wL .mul wd) .mul wR in f32 (M.cpp:3274); 0 outside the window
+                const float w = *reinterpret_cast<const float*>(wlp + c4) * *reinterpret_cast<const float*>(wrq + c4);
+                run = r == 0 ? (double)w : run + (double)w;
                 pre[r] = run;
-                mb = (mb << 1) | (cell != NC ? 1u : 0u);
+                mb = (mb << 1) | (c4 != 4u * NC ? 1u : 0u);
             }
             const double incl = wave_inclusive_scan(run);
             const double half = readlane_f64(incl, 63) * 0.5;  // cv::sum(weight_img_win)[0] / 2, M.cpp:3284
@@ -238,8 +247,16 @@ int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, cons
     const int nbx = (W + BW - 1) / BW, nby = (H + BH - 1) / BH;
     hipLaunchKernelGGL(k_wm_sort_regions, dim3((unsigned)(nbx * nby), (unsigned)((d_count + 3) / 4)), dim3(256), 0, s, cost, H, W, nbx,
                        d_begin, d_count, listC, listP);
-    hipLaunchKernelGGL(k_wm_pick, dim3((unsigned)(nbx * nby)), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx, numD,
-                       max_off, d_begin, d_count, out);
+    static const int nsplit = [] { const char* e = getenv("ASW_WMEDIAN_TILE_SPLIT"); return e ? atoi(e) : 2; }();  // A/B only
+    if (nsplit == 1)
+        hipLaunchKernelGGL(k_wm_pick<1>, dim3((unsigned)(nbx * nby), 1), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
+                           numD, max_off, d_begin, d_count, out);
+    else if (nsplit == 4)
+        hipLaunchKernelGGL(k_wm_pick<4>, dim3((unsigned)(nbx * nby), 4), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
+                           numD, max_off, d_begin, d_count, out);
+    else
+        hipLaunchKernelGGL(k_wm_pick<2>, dim3((unsigned)(nbx * nby), 2), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
+                           numD, max_off, d_begin, d_count, out);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
