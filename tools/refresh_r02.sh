@@ -19,13 +19,17 @@ ASW_GEODESIC_XQ=0 bench geodesic_one_kernel --workload geodesic $KITTI --frames 
 bench guided2 --workload guided2 --frames 4 --steps 3
 bench guided --workload guided --frames 4 --steps 3
 bench wmedian --workload wmedian $KITTI --frames 4 --steps 3
+ASW_WMEDIAN_TILE=0 bench wmedian_per_pixel_sort --workload wmedian $KITTI --frames 4 --steps 3 --no-cpu --batch-frames 0
 stats bilateral_bench "$ROOT/bench.py" --no-cpu --batch-frames 0
 stats alg2 "$ROOT/tools/run_one.py" --alg 2 --reps 5
 stats alg4 "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 4
 stats alg8 "$ROOT/tools/run_one.py" --alg 8 --reps 3
+stats alg10 "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 3
+ASW_WMEDIAN_TILE=0 stats alg10_per_pixel_sort "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 2
 pmc bilateral_FETCH_SIZE "FETCH_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc bilateral_WRITE_SIZE "WRITE_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc bilateral_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 2 --reps 2
+pmc wmedian_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 2
 pmc geodesic_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 2
 pmc geodesic_FETCH_SIZE "FETCH_SIZE" "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 2
 pmc geodesic_WRITE_SIZE "WRITE_SIZE" "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 2
