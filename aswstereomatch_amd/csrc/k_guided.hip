@@ -34,9 +34,13 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 //     has entered (NaN - NaN = NaN), whereas a window sum is NaN only while the NaN is inside the window -- the form the CPU
 //     restatement defines.  Whenever a running sum is not finite it is therefore rebuilt from the k rows of its window (and
 //     the shared horizontal sum of the second column from its own k terms); finite data never takes these branches.
-template <int NP, int CPL, int ND, int WPE, bool NANSAFE, class Src, class Dst>
-__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
+// KT: the window size when it is known at compile time (15: the reference's call site), 0 = run-time k.  With a run-time k
+// the horizontal sum is a loop of dependent LDS round trips (8 terms, then one per iteration); with KT its 16 doubles per plane
+// are read at once.
+template <int NP, int CPL, int ND, int WPE, bool NANSAFE, int KT, class Src, class Dst>
+__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k_rt, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
 {
+    const int k = KT ? KT : k_rt;
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
     // the wavefront index is uniform within a wavefront: as an SGPR it makes strip, band, slice and every base address
@@ -168,11 +172,23 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const double* b = hs + (n * NP + p) * (SW + 2) + c0;
-                        double sum = 0.0;
-                        for (int i = 0; i < k; i++) sum = sum + b[i];
+                        double sum = 0.0, b0, bk = 0.0;
+                        if constexpr (KT > 0) {
+                            double bb[KT + 1];
+#pragma unroll
+                            for (int i = 0; i < KT + (CPL > 1 ? 1 : 0); i++) bb[i] = b[i];
+#pragma unroll
+                            for (int i = 0; i < KT; i++) sum = sum + bb[i];
+                            b0 = bb[0];
+                            if constexpr (CPL > 1) bk = bb[KT];
+                        } else {
+                            for (int i = 0; i < k; i++) sum = sum + b[i];
+                            b0 = b[0];
+                            if constexpr (CPL > 1) bk = b[k];
+                        }
                         m[0][p] = (float)(sum * scale);
                         if constexpr (CPL > 1) {
-                            double sum1 = (sum - b[0]) + b[k];  // window of the adjacent column
+                            double sum1 = (sum - b0) + bk;  // window of the adjacent column
                             if constexpr (NANSAFE) {
                                 if (!__builtin_isfinite(sum1)) {
                                     sum1 = 0.0;
@@ -566,7 +582,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n_eff + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
-    auto kern = k_box_walk<NP, CPL, ND, WPE, NANSAFE, Src, Dst>;
+    auto kern = k == 15 ? k_box_walk<NP, CPL, ND, WPE, NANSAFE, 15, Src, Dst> : k_box_walk<NP, CPL, ND, WPE, NANSAFE, 0, Src, Dst>;
     // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
     // GuidedF_2 -1 %); four strips of the one slice otherwise
     const int slice_par = (n + ND - 1) / ND >= 4 ? 1 : 0;
