@@ -198,11 +198,13 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             }
             const double incl = wave_inclusive_scan(run);
             const double half = readlane_f64(incl, 63) * 0.5;  // cv::sum(weight_img_win)[0] / 2, M.cpp:3284
-            const double excl = incl - run;
+            // first entry whose prefix (exclusive prefix of the lane + local prefix) exceeds half: compared as
+            // pre[r] > half - excl, one subtraction per lane instead of one addition per entry
+            const double thr = half - (incl - run);
             int first = KPL;
 #pragma unroll
             for (int r = KPL - 1; r >= 0; r--)
-                if (excl + pre[r] > half) first = r;
+                if (pre[r] > thr) first = r;
             const unsigned long long ball = __ballot(first < KPL);
             float res = 0.0f;
             if (ball) {  // wave-uniform
