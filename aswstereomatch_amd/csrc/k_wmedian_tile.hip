@@ -90,8 +90,14 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64(double v)  // lanes without a source (row edge, masked rows) read 0
 {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, ROWMASK, 0xf, false);
+    int lo, hi;
+    if constexpr (ROWMASK == 0xf) {  // shifts inside a row: bound_ctrl supplies the zeros, no 'old' operand to initialise
+        lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, true);
+    } else {                         // row broadcasts into some rows only: the other rows keep old = 0
+        lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, ROWMASK, 0xf, false);
+    }
     return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
 }
 
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
 {
     constexpr int NPART = NPIX / NSPLIT;
     __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels, slot 225 = 0
-    __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: wR row of the pixel a wavefront is working on, slot 225 = 0
+    __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: weights of the pixel a wavefront is working on at its d, slot 225 = 0
     __shared__ uint16_t sT[NT + 1];           // relative position -> byte offset of the cell in a weight row (900 = zero slot)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
@@ -173,16 +179,19 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
         fetch(p_begin);  // the first pixel of a part always exists
         for (int p = p_begin; p < p_begin + NPART; p++) {
             if (!valid(p)) continue;  // wave-uniform
+            // the pixel's 225 weights (wL .mul wd) .mul wR -- f32, in the reference's order, M.cpp:3274 -- are formed here,
+            // one cell per lane (conflict-free reads of the pixel's wL row), so that the walk below gathers ONE value per
+            // entry: the gathers hit random banks and were what bound the kernel (two per entry: 24 of 25 ms LDS-busy)
+            const float* wl_row = sWL + (p - p_begin) * WLS;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (lane + 64 * k < NC) wrp[lane + 64 * k] = nxt[k];
+                if (lane + 64 * k < NC) wrp[lane + 64 * k] = wl_row[lane + 64 * k] * nxt[k];
             int pn = p + 1;
             while (pn < p_begin + NPART && !valid(pn)) pn++;
             if (pn < p_begin + NPART) fetch(pn);  // in flight under this pixel's arithmetic
             __builtin_amdgcn_wave_barrier();
 
-            const char* wlp = reinterpret_cast<const char*>(sWL + (p - p_begin) * WLS);
-            const char* wrq = reinterpret_cast<const char*>(wrp);
+            const char* wq = reinterpret_cast<const char*>(wrp);
             const int base7 = (p >> 3) * 32 + (p & 7) - HW;
             double run = 0.0, pre[KPL];
             uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit 7 - r
@@ -190,8 +199,7 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             for (int r = 0; r < KPL; r++) {
                 const uint32_t t = min((uint32_t)(pos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
                 const uint32_t c4 = sT[t];
-                // (wL .mul wd) .mul wR in f32 (M.cpp:3274); 0 outside the window
-                const float w = *reinterpret_cast<const float*>(wlp + c4) * *reinterpret_cast<const float*>(wrq + c4);
+                const float w = *reinterpret_cast<const float*>(wq + c4);  // the cell's weight; 0 outside the window (zero slot)
                 run = r == 0 ? (double)w : run + (double)w;
                 pre[r] = run;
                 mb = (mb << 1) | (c4 != 4u * NC ? 1u : 0u);
