@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             if (!valid(p)) continue;  // wave-uniform
             // the pixel's 225 weights (wL .mul wd) .mul wR -- f32, in the reference's order, M.cpp:3274 -- are formed here,
             // one cell per lane (conflict-free reads of the pixel's wL row), so that the walk below gathers ONE value per
-            // entry: the gathers hit random banks and were what bound the kernel (two per entry: 24 of 25 ms LDS-busy)
+            // entry: the gathers hit random banks and were what bound the kernel (SQ_LDS_BANK_CONFLICT was half of the LDS cycles)
             const float* wl_row = sWL + (p - p_begin) * WLS;
 #pragma unroll
             for (int k = 0; k < 4; k++)
