@@ -120,9 +120,23 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // grid (blocks, NSPLIT), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, the 64 / NSPLIT pixels
 // (whole rows of the block) of this workgroup's part.  NSPLIT = 2 halves the LDS weight slab: four workgroups per CU.
-template <int NSPLIT>
+// COMPACT (NSPLIT = 4, two pixel rows per part): the windows of the part cover 16 of the region's 22 rows, so each wavefront
+// first drops the entries of the other rows from its list (a prefix-sum scatter through LDS that keeps the sorted order):
+// 352 entries in 384 slots, 6 per lane instead of 8 in every walk.
+template <int NSPLIT, bool COMPACT>
 __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __restrict__ wLd /* [H][W][225] */,
                                                              const float* __restrict__ wRb /* [H][Wb][225] */,
                                                              const uint32_t* __restrict__ listC, const uint16_t* __restrict__ listP,
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
     __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels, slot 225 = 0
     __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: weights of the pixel a wavefront is working on at its d, slot 225 = 0
     __shared__ uint16_t sT[NT + 1];           // relative position -> byte offset of the cell in a weight row (900 = zero slot)
+    constexpr int KE = COMPACT ? 6 : KPL;     // list entries per lane in the walk
+    __shared__ uint32_t sC[COMPACT ? PICK_WAVES : 1][COMPACT ? 64 * KE : 1];  // compaction buffer (original slot << 16 | position)
+    static_assert(!COMPACT || NSPLIT == 4, "the compacted list holds the 16 region rows of a two-row part");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
     const int x0 = bx * BW, y0 = by * BH;
@@ -163,6 +180,37 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
         const int pos[KPL] = {(int)(pp.x & 0xffffu), (int)(pp.x >> 16), (int)(pp.y & 0xffffu), (int)(pp.y >> 16),
                               (int)(pp.z & 0xffffu), (int)(pp.z >> 16), (int)(pp.w & 0xffffu), (int)(pp.w >> 16)};
         float* od = out + (size_t)d * plane;
+        int epos[KE];       // positions of the entries the walk visits
+        uint32_t eslot[KE]; // COMPACT: their slot (lane * 8 + r) in the full list, where the cost bits are
+        if constexpr (COMPACT) {
+            const int ly0 = p_begin >> 3;
+            bool keep[KPL];
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < KPL; r++) {
+                keep[r] = (uint32_t)((pos[r] >> 5) - ly0) < 16u;  // padding entries (row 31) never stay
+                cnt += keep[r] ? 1 : 0;
+            }
+            uint32_t* cb = sC[wv];
+#pragma unroll
+            for (int i = 0; i < KE; i++) cb[lane + 64 * i] = POS_PAD;  // slots behind the last kept entry: never a member
+            int o = wave_inclusive_scan(cnt) - cnt;
+#pragma unroll
+            for (int r = 0; r < KPL; r++) {
+                if (keep[r]) cb[o] = ((uint32_t)(lane * KPL + r) << 16) | (uint32_t)pos[r];
+                o += keep[r] ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < KE; i++) {
+                const uint32_t e = cb[lane * KE + i];
+                epos[i] = (int)(e & 0xffffu);
+                eslot[i] = e >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KE; i++) { epos[i] = pos[i]; eslot[i] = 0; }
+        }
 
         // right-image weight row of pixel p at this d: weightWinsR[y][x - offset + numDisparity - 1] (M.cpp:3274)
         float nxt[4];
@@ -193,11 +241,11 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
 
             const char* wq = reinterpret_cast<const char*>(wrp);
             const int base7 = (p >> 3) * 32 + (p & 7) - HW;
-            double run = 0.0, pre[KPL];
-            uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit 7 - r
+            double run = 0.0, pre[KE];
+            uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit KE - 1 - r
 #pragma unroll
-            for (int r = 0; r < KPL; r++) {
-                const uint32_t t = min((uint32_t)(pos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
+            for (int r = 0; r < KE; r++) {
+                const uint32_t t = min((uint32_t)(epos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
                 const uint32_t c4 = sT[t];
                 const float w = *reinterpret_cast<const float*>(wq + c4);  // the cell's weight; 0 outside the window (zero slot)
                 run = r == 0 ? (double)w : run + (double)w;
@@ -209,17 +257,17 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             // first entry whose prefix (exclusive prefix of the lane + local prefix) exceeds half: compared as
             // pre[r] > half - excl, one subtraction per lane instead of one addition per entry
             const double thr = half - (incl - run);
-            int first = KPL;
+            int first = KE;
 #pragma unroll
-            for (int r = KPL - 1; r >= 0; r--)
+            for (int r = KE - 1; r >= 0; r--)
                 if (pre[r] > thr) first = r;
-            const unsigned long long ball = __ballot(first < KPL);
+            const unsigned long long ball = __ballot(first < KE);
             float res = 0.0f;
             if (ball) {  // wave-uniform
                 const int fl = __ffsll((long long)ball) - 1;
                 const int fr = __builtin_amdgcn_readlane(first, fl);
                 const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)mb, fl);
-                const uint32_t before = bits >> (8 - fr);  // members among entries 0 .. fr-1 of that lane, entry fr-1 at bit 0
+                const uint32_t before = bits >> (KE - fr);  // members among entries 0 .. fr-1 of that lane, entry fr-1 at bit 0
                 int pl = fl, pr = fr;  // the crossing element itself if nothing precedes it (M.cpp:3293-3296)
                 if (before) {
                     pr = fr - 1 - __builtin_ctz(before);
@@ -227,8 +275,16 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
                     const unsigned long long lower = __ballot(mb != 0u) & ((1ull << fl) - 1ull);
                     if (lower) {
                         pl = 63 - __builtin_clzll(lower);
-                        pr = 7 - __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)mb, pl));  // its last member
+                        pr = KE - 1 - __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)mb, pl));  // its last member
                     }
+                }
+                if constexpr (COMPACT) {  // (pl, pr) addresses the compacted list: back to the slot that holds the cost
+                    uint32_t ss = eslot[0];
+#pragma unroll
+                    for (int q = 1; q < KE; q++) ss = pr == q ? eslot[q] : ss;
+                    const int slot = __builtin_amdgcn_readlane((int)ss, pl);
+                    pl = slot >> 3;
+                    pr = slot & 7;
                 }
                 uint32_t sel = cst[0];
 #pragma unroll
@@ -257,16 +313,18 @@ int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, cons
     const int nbx = (W + BW - 1) / BW, nby = (H + BH - 1) / BH;
     hipLaunchKernelGGL(k_wm_sort_regions, dim3((unsigned)(nbx * nby), (unsigned)((d_count + 3) / 4)), dim3(256), 0, s, cost, H, W, nbx,
                        d_begin, d_count, listC, listP);
-    static const int nsplit = [] { const char* e = getenv("ASW_WMEDIAN_TILE_SPLIT"); return e ? atoi(e) : 2; }();  // A/B only
+    // A/B only: 1 | 2 | 4 = parts per block without compaction, 0 (default) = four parts with the compacted lists
+    static const int nsplit = [] { const char* e = getenv("ASW_WMEDIAN_TILE_SPLIT"); return e ? atoi(e) : 0; }();
+    const dim3 blk(64 * PICK_WAVES);
+    const unsigned nb = (unsigned)(nbx * nby);
     if (nsplit == 1)
-        hipLaunchKernelGGL(k_wm_pick<1>, dim3((unsigned)(nbx * nby), 1), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
-                           numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<1, false>), dim3(nb, 1), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
+    else if (nsplit == 2)
+        hipLaunchKernelGGL((k_wm_pick<2, false>), dim3(nb, 2), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     else if (nsplit == 4)
-        hipLaunchKernelGGL(k_wm_pick<4>, dim3((unsigned)(nbx * nby), 4), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
-                           numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<4, false>), dim3(nb, 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     else
-        hipLaunchKernelGGL(k_wm_pick<2>, dim3((unsigned)(nbx * nby), 2), dim3(64 * PICK_WAVES), 0, s, wLd, wRb, listC, listP, H, W, nbx,
-                           numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<4, true>), dim3(nb, 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
