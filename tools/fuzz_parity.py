@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
                     "both directions, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
+    ap.add_argument("--wm15", type=float, default=0.0, help="share of the cases forced to the 15x15 weighted median (the tile form, k_wmedian_tile.hip)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = asw.Context(0)
@@ -84,6 +85,9 @@ def main():
                 for img in (L, R):
                     y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
                     img[y0:y0 + int(rng.integers(1, 6)), x0:x0 + int(rng.integers(1, 60))] = rng.integers(0, 256, 3).astype(np.uint8)
+        if rng.random() < args.wm15:
+            method, win, dt = "wmedian", 15, 0
+            numD = int(rng.integers(1, 40))
         tag = (method, H, W, win, minD, numD, dt, seed)
         if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
             ctx.close()

@@ -24,11 +24,16 @@ stats bilateral_bench "$ROOT/bench.py" --no-cpu --batch-frames 0
 stats alg2 "$ROOT/tools/run_one.py" --alg 2 --reps 5
 stats alg4 "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 4
 stats alg8 "$ROOT/tools/run_one.py" --alg 8 --reps 3
+stats alg7 "$ROOT/tools/run_one.py" --alg 7 --reps 3
 stats alg10 "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 3
 ASW_WMEDIAN_TILE=0 stats alg10_per_pixel_sort "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 2
 pmc bilateral_FETCH_SIZE "FETCH_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc bilateral_WRITE_SIZE "WRITE_SIZE" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc bilateral_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 2 --reps 2
+LDSQ="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
+pmc wmedian_LDS "$LDSQ" "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 1
+pmc guided2_SQ "$LDSQ" "$ROOT/tools/run_one.py" --alg 8 --reps 1
+pmc bilateral_LDS "$LDSQ" "$ROOT/tools/run_one.py" --alg 2 --reps 2
 pmc wmedian_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 10 $KITTI --reps 2
 pmc geodesic_SQ "$SQ" "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 2
 pmc geodesic_FETCH_SIZE "FETCH_SIZE" "$ROOT/tools/run_one.py" --alg 4 $KITTI --reps 2
