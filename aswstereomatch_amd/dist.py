@@ -4,7 +4,31 @@ Frames are independent, so ranks never exchange image data: the process group ca
 barrier around the timed region and the MAX over ranks of the elapsed time.  backend "nccl" is RCCL on
 ROCm; "gloo" is used by the CPU tests.
 """
+import contextlib
 import os
+import sys
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File descriptor 1 -> 2 for the duration: the communication libraries print banners on stdout while a process group
+    is built (RCCL's version block under NCCL_DEBUG=VERSION, gloo's "Rank 0 is connected ..."), and rank 0's stdout is
+    the bench's one JSON line.  C stdio is flushed inside the redirection so that nothing surfaces later."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def env_ranks():
@@ -21,15 +45,35 @@ class Group:
         self.rank, self.local_rank, self.world = env_ranks()
         self.dist = None
         self.device = device
+        self.backend = "none"
         if self.world > 1:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            kw = {}
-            if backend == "nccl" and device is not None:
-                kw["device_id"] = device
-            dist.init_process_group(backend=backend or "gloo", rank=self.rank, world_size=self.world, **kw)
+            with _stdout_to_stderr():
+                self.backend = backend or "gloo"
+                kw = {}
+                if self.backend == "nccl" and device is not None:
+                    kw["device_id"] = device  # eager communicator on this rank's own GPU: a failure shows here, on every rank
+                try:
+                    dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world, **kw)
+                except Exception as e:  # noqa: BLE001 -- RCCL could not build the communicator (it fails on all ranks alike)
+                    if self.backend != "nccl":
+                        raise
+                    # The group carries a barrier and two scalar all-reduces, never image data: gloo over the loopback does
+                    # that as well.  A second rendezvous needs its own port (rank 0's first store may still hold the old one).
+                    print("dist: RCCL process group failed (%s); falling back to gloo for the barrier / timing reductions" % str(e).splitlines()[0],
+                          file=sys.stderr, flush=True)
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+                    self.backend = "gloo"
+                    self.device = None
+                    dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()
             self.dist = dist
 
     def barrier(self):

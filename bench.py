@@ -120,7 +120,7 @@ def parse_args(argv=None):
                     help="frames of the asw_stereo_match_batch leg over all --gpus devices (C5: 64); 0 skips it")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals: implied by --dry-run and --oversubscribe)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks wrap over the devices)")
     ap.add_argument("--dry-run", action="store_true",
@@ -213,8 +213,8 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or drop the launcher and let "
                          "--gpus N start the ranks)" % (args.gpus, world))
-    if args.dry_run and args.backend == "nccl":
-        args.backend = "gloo"
+    if (args.dry_run or args.oversubscribe) and args.backend == "nccl" and not os.environ.get("ASW_BENCH_KEEP_BACKEND"):
+        args.backend = "gloo"  # no GPU at all / ranks sharing a GPU (RCCL refuses two ranks on one device): rehearsals only
     if args.fail_rank >= 0 and not args.dry_run:
         raise SystemExit("--fail-rank is a --dry-run test hook")
 
@@ -319,7 +319,7 @@ def main(argv=None):
             "config": {"workload": "%dx%d D=%d win=%d %s, %d frames/GPU/step resident in HBM, cost volume kept"
                                    % (W, H, D, args.win, args.workload, args.frames),
                        "frames_per_gpu_per_step": args.frames, "candidates": ncand, "parallelism": "frames sharded, no collective",
-                       "ranks": world, "rank_pids": pids, "backend": args.backend if world > 1 else "none"},
+                       "ranks": world, "rank_pids": pids, "backend": group.backend if world > 1 else "none"},
         }
         if args.dry_run:
             out["dry_run"] = True

@@ -20,8 +20,10 @@ def _clean_env():
 
 
 def _json_line(stdout):
-    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout  # rank 0 prints ONE JSON line, the other ranks print nothing
+    lines = stdout.strip().splitlines()
+    # rank 0 prints ONE JSON line and NOTHING else on stdout (the banners gloo / RCCL print while a process group is built are
+    # sent to stderr, aswstereomatch_amd/dist.py); the other ranks print nothing
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
