@@ -10,7 +10,7 @@ from aswstereomatch_amd.synth import make_pair, shifted_pair
 
 pytestmark = pytest.mark.gpu
 A = asw.StereoMatchingAlgorithms
-LEFT = asw.DISPARITY_LEFT
+LEFT, RIGHT = asw.DISPARITY_LEFT, asw.DISPARITY_RIGHT
 
 
 @pytest.fixture(scope="module")
@@ -54,6 +54,25 @@ def test_c5_frame_1080p_classic_rows_vs_oracle(ctx, oracle):
         assert np.array_equal(v[:, rows[0]:rows[1]], vw[:, rows[0]:rows[1]])
     d2 = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT, 15, 0, 128)
     assert np.array_equal(d, d2)   # bit-deterministic
+
+
+def test_c5_frame_1080p_classic_right_rows_vs_oracle(ctx, oracle):
+    # the same frame with DISPARITY_RIGHT (row f2; M.cpp:1113-1142): the xq kernel's RIGHT instantiation, its border tile (the
+    # first of a row) and the one-candidate tail at full size, against oracle row bands and against the one-kernel path
+    import os
+    L, R, _ = make_pair(1080, 1920, 128, seed=1234)
+    d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
+    assert v.shape == (129, 1080, 1920) and _wta_consistent(d, v)
+    for rows in ((0, 3), (700, 703), (1077, 1080)):
+        rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 1, 15, 0, 128, want_vol=True, rows=rows)
+        assert np.array_equal(d[rows[0]:rows[1]], dw[rows[0]:rows[1]])
+        assert np.array_equal(v[:, rows[0]:rows[1]], vw[:, rows[0]:rows[1]])
+    os.environ["ASW_BILATERAL_XQ"] = "0"
+    try:
+        d0, v0 = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
+    finally:
+        del os.environ["ASW_BILATERAL_XQ"]
+    assert np.array_equal(d, d0) and np.array_equal(v, v0, equal_nan=True)
 
 
 def test_c3_1080p_guided2_properties(ctx):
