@@ -138,6 +138,10 @@ def test_c4_kitti_geodesic_and_wmedian_whole_frame_vs_oracle(ctx, oracle):
     rc, dw, vw = oracle.asw_wmedian(L, R, 0, 15, 10, 10, 0, 192, want_vol=True)
     assert rc == 0 and vw.shape == v.shape == (192, 375, 1242)
     assert np.array_equal(v, vw) and np.array_equal(d, dw)
+    # DISPARITY_RIGHT of the geodesic method (row f2; M.cpp:1498-1520), whole frame
+    d, v = ctx.computeAdaptiveWeight_geodesic(L, R, RIGHT, 15, 0, 192, return_cost_volume=True)
+    rc, dw, vw = oracle.asw_geodesic(L, R, 1, 15, 0, 192, want_vol=True)
+    assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
 
 
 def test_c5_1080p_batch_of_8_equals_single_frames(ctx):
