@@ -171,6 +171,9 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
     __syncthreads();
 
     float* wrp = sWR[wv];
+    unsigned long long vmask = 0;
+    for (int q = 0; q < NPART; q++)
+        if (x0 + ((p_begin + q) & 7) < W && y0 + ((p_begin + q) >> 3) < H) vmask |= 1ull << q;
     for (int dd = wv; dd < d_count; dd += PICK_WAVES) {
         const int d = d_begin + dd;
         const size_t lbase = ((size_t)blk * d_count + dd) * SLOTS + (size_t)lane * KPL;
@@ -223,10 +226,12 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
                 nxt[k] = c < NC ? row[c] : 0.0f;
             }
         };
-        auto valid = [&](int p) { return x0 + (p & 7) < W && y0 + (p >> 3) < H; };
+        // pixels of the part that lie in the image, as a bit mask (wave-uniform): the loop visits the set bits
+        unsigned long long todo = vmask;
         fetch(p_begin);  // the first pixel of a part always exists
-        for (int p = p_begin; p < p_begin + NPART; p++) {
-            if (!valid(p)) continue;  // wave-uniform
+        while (todo) {
+            const int p = p_begin + __builtin_ctzll(todo);
+            todo &= todo - 1;
             // the pixel's 225 weights (wL .mul wd) .mul wR -- f32, in the reference's order, M.cpp:3274 -- are formed here,
             // one cell per lane (conflict-free reads of the pixel's wL row), so that the walk below gathers ONE value per
             // entry: the gathers hit random banks and were what bound the kernel (SQ_LDS_BANK_CONFLICT was half of the LDS cycles)
@@ -234,9 +239,7 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (lane + 64 * k < NC) wrp[lane + 64 * k] = wl_row[lane + 64 * k] * nxt[k];
-            int pn = p + 1;
-            while (pn < p_begin + NPART && !valid(pn)) pn++;
-            if (pn < p_begin + NPART) fetch(pn);  // in flight under this pixel's arithmetic
+            if (todo) fetch(p_begin + __builtin_ctzll(todo));  // the next pixel's row: in flight under this pixel's arithmetic
             __builtin_amdgcn_wave_barrier();
 
             const char* wq = reinterpret_cast<const char*>(wrp);
