@@ -120,6 +120,22 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// a[r] of lane l for wave-uniform r and l: a branch tree on the scalar unit and two v_readlane, instead of a chain of
+// v_cndmask (each with its s_cmp / s_cselect) over all N registers
+template <int N>
+__device__ __forceinline__ uint32_t pick_reg(const uint32_t (&a)[N], int r, int l)
+{
+    static_assert(N == 6 || N == 8, "");
+#define ASW_RL(i) (uint32_t)__builtin_amdgcn_readlane((int)a[(i) < N ? (i) : N - 1], l)
+    if (r < 4) {
+        if (r < 2) return r == 0 ? ASW_RL(0) : ASW_RL(1);
+        return r == 2 ? ASW_RL(2) : ASW_RL(3);
+    }
+    if (r < 6) return r == 4 ? ASW_RL(4) : ASW_RL(5);
+    return r == 6 ? ASW_RL(6) : ASW_RL(7);
+#undef ASW_RL
+}
+
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
     v += __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true);
@@ -282,17 +298,11 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
                     }
                 }
                 if constexpr (COMPACT) {  // (pl, pr) addresses the compacted list: back to the slot that holds the cost
-                    uint32_t ss = eslot[0];
-#pragma unroll
-                    for (int q = 1; q < KE; q++) ss = pr == q ? eslot[q] : ss;
-                    const int slot = __builtin_amdgcn_readlane((int)ss, pl);
+                    const int slot = (int)pick_reg(eslot, pr, pl);
                     pl = slot >> 3;
                     pr = slot & 7;
                 }
-                uint32_t sel = cst[0];
-#pragma unroll
-                for (int q = 1; q < KPL; q++) sel = pr == q ? cst[q] : sel;
-                res = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sel, pl));
+                res = __uint_as_float(pick_reg(cst, pr, pl));
             }
             if (lane == 0) od[(size_t)(y0 + (p >> 3)) * W + x0 + (p & 7)] = res;
         }
