@@ -223,12 +223,12 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
 #pragma unroll
             for (int i = 0; i < KE; i++) {
                 const uint32_t e = cb[lane * KE + i];
-                epos[i] = (int)(e & 0xffffu);
+                epos[i] = 2 * (int)(e & 0xffffu);  // twice the position: the byte offset into the u16 table needs no shift per pixel
                 eslot[i] = e >> 16;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < KE; i++) { epos[i] = pos[i]; eslot[i] = 0; }
+            for (int i = 0; i < KE; i++) { epos[i] = 2 * pos[i]; eslot[i] = 0; }
         }
 
         // right-image weight row of pixel p at this d: weightWinsR[y][x - offset + numDisparity - 1] (M.cpp:3274)
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             __builtin_amdgcn_wave_barrier();
 
             const char* wq = reinterpret_cast<const char*>(wrp);
-            const int base7 = (p >> 3) * 32 + (p & 7) - HW;
+            const int base7x2 = 2 * ((p >> 3) * 32 + (p & 7) - HW);
             double run = 0.0, pre[KE];
             uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit KE - 1 - r
 #pragma unroll
             for (int r = 0; r < KE; r++) {
-                const uint32_t t = min((uint32_t)(epos[r] - base7), (uint32_t)(NT - 1));  // rows above the window wrap to huge values
-                const uint32_t c4 = sT[t];
+                const uint32_t t2 = min((uint32_t)(epos[r] - base7x2), (uint32_t)(2 * (NT - 1)));  // rows above the window wrap to huge values
+                const uint32_t c4 = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(sT) + t2);
                 const float w = *reinterpret_cast<const float*>(wq + c4);  // the cell's weight; 0 outside the window (zero slot)
                 run = r == 0 ? (double)w : run + (double)w;
                 pre[r] = run;
