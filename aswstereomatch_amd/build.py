@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
-]
+] + os.environ.get("HIPCC_EXTRA", "").split()  # measurement builds, e.g. -DASW_XQ_ABLATION (tools/prof_bilateral.sh)
 
 
 def _newer(a, b):

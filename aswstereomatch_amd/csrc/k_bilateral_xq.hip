@@ -413,10 +413,14 @@ int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, 
     }
     // tiles whose windows (of in-image pixels) stay left of the right border: x0 + 63 + 7 <= W - 1
     const int n_int = W >= PXW + HH ? std::min(ntiles, (W - PXW - HH) / PXW + 1) : 0;
+#ifdef ASW_XQ_ABLATION  // measurement builds only (HIPCC_EXTRA=-DASW_XQ_ABLATION): the ablated kernels compute wrong results
     int abl = 0;
-    if (const char* e = getenv("ASW_XQ_ABLATE")) abl = atoi(e) & 3;  // timing experiments only (profiles/r02/ablation_*.csv)
+    if (const char* e = getenv("ASW_XQ_ABLATE")) abl = atoi(e) & 3;  // profiles/r02/ablation/*.csv
     auto ki = abl == 0 ? k_asw_bilateral_xq<false, 0, false> : abl == 1 ? k_asw_bilateral_xq<false, 1, false>
             : abl == 2 ? k_asw_bilateral_xq<false, 2, false> : k_asw_bilateral_xq<false, 3, false>;
+#else
+    auto ki = k_asw_bilateral_xq<false, 0, false>;
+#endif
     auto ke = k_asw_bilateral_xq<true, 0, false>;
     if (n_int > 0) {
         XqParams p{H, W, minD, 0};

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Kernel-level profile of the classic bilateral path on the GPU box (1080p D=128 win 15):
 #   /usr/local/graft/bin/gpurun --timeout 600 -- 'bash tools/prof_bilateral.sh <tag> [variants...]'
-# per ASW_XQ_ABLATE value (0 = the product; 1 no staging, 2 no barriers, 3 both: timing experiments) or "old": rocprofv3 kernel stats of tools/run_one.py and two SQ counter passes (separate runs, --pmc never
+# per ASW_XQ_ABLATE value (0 = the product; 1 no staging, 2 no barriers, 3 both: timing experiments -- these need a library
+# built with  HIPCC_EXTRA=-DASW_XQ_ABLATION python -m aswstereomatch_amd.build --force;  the shipped build ignores the variable) or "old": rocprofv3 kernel stats of tools/run_one.py and two SQ counter passes (separate runs, --pmc never
 # combined with other trace domains).  Output: gpurun_out/<tag>/.
 set -e -o pipefail
 TAG=${1:-bil}; shift || true
