@@ -171,21 +171,36 @@ int check_pair(const asw_image* L, const asw_image* R)
     return ASW_OK;
 }
 
-// Pitched host image <-> dense device plane.  Rows without padding are one 1-D copy: hipMemcpy2DAsync on pageable memory takes
+// Pitched host image <-> dense device plane.  Rows without padding are one 1-D copy.  hipMemcpy2DAsync on pageable memory takes
 // milliseconds when the row length is not a multiple of the DMA granule (1242 x 3 bytes per row: 6.7 ms per call for the three
-// copies of a KITTI-shape frame, against 0.9 ms at 1920 x 3), whatever the pitch.
-static hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t rowbytes, size_t rows, hipMemcpyKind kind,
-                            hipStream_t s)
+// copies of a KITTI-shape frame, against 0.9 ms at 1920 x 3), whatever the pitch -- so padded rows are packed / unpacked on the
+// host through a dense staging buffer of the context and travel as a 1-D copy as well.
+static hipError_t copy_rows(asw_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t rowbytes, size_t rows,
+                            hipMemcpyKind kind)
 {
+    hipStream_t s = ctx->stream;
     if (dpitch == rowbytes && spitch == rowbytes) return hipMemcpyAsync(dst, src, rowbytes * rows, kind, s);
-    return hipMemcpy2DAsync(dst, dpitch, src, spitch, rowbytes, rows, kind, s);
+    ctx->host_pack.resize(rowbytes * rows);
+    unsigned char* pack = ctx->host_pack.data();
+    if (kind == hipMemcpyHostToDevice) {  // the device side is dense
+        for (size_t y = 0; y < rows; y++) memcpy(pack + y * rowbytes, (const unsigned char*)src + y * spitch, rowbytes);
+        hipError_t e = hipMemcpyAsync(dst, pack, rowbytes * rows, kind, s);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(s);  // the staging buffer is reused by the next image
+    }
+    hipError_t e = hipMemcpyAsync(pack, src, rowbytes * rows, kind, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    for (size_t y = 0; y < rows; y++) memcpy((unsigned char*)dst + y * dpitch, pack + y * rowbytes, rowbytes);
+    return hipSuccess;
 }
 
 int upload_image(asw_ctx* ctx, const asw_image* im, DevBuf& dst)
 {
     size_t rowbytes = (size_t)im->cols * im->channels;
     ASW_TRY(dst.ensure(rowbytes * im->rows));
-    ASW_HIP_TRY(copy_rows(dst.p, rowbytes, im->data, im->step, rowbytes, im->rows, hipMemcpyHostToDevice, ctx->stream));
+    ASW_HIP_TRY(copy_rows(ctx, dst.p, rowbytes, im->data, im->step, rowbytes, im->rows, hipMemcpyHostToDevice));
     return ASW_OK;
 }
 
@@ -324,8 +339,8 @@ extern "C" int asw_download_pair(asw_ctx* ctx, int slot, asw_image* left, asw_im
         if (im->depth != ASW_8U || im->rows != f->rows || im->cols != f->cols || im->channels != f->channels || im->step < rowbytes)
             return ASW_ERR_BAD_ARGUMENT;
     ASW_HIP_TRY(hipSetDevice(ctx->device));
-    ASW_HIP_TRY(copy_rows(left->data, left->step, f->L.p, rowbytes, rowbytes, f->rows, hipMemcpyDeviceToHost, ctx->stream));
-    ASW_HIP_TRY(copy_rows(right->data, right->step, f->R.p, rowbytes, rowbytes, f->rows, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(copy_rows(ctx, left->data, left->step, f->L.p, rowbytes, rowbytes, f->rows, hipMemcpyDeviceToHost));
+    ASW_HIP_TRY(copy_rows(ctx, right->data, right->step, f->R.p, rowbytes, rowbytes, f->rows, hipMemcpyDeviceToHost));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
 }
@@ -345,7 +360,7 @@ extern "C" int asw_download_disparity_u8(asw_ctx* ctx, int slot, asw_image* disp
     ASW_TRY(u8.ensure(n));
     ASW_TRY(mm.ensure(2 * sizeof(int)));
     ASW_TRY(launch_disp_to_u8(ctx->stream, f->disp.as<float>(), n, normalize, u8.as<uint8_t>(), mm.as<int>()));
-    ASW_HIP_TRY(copy_rows(disp_u8->data, disp_u8->step, u8.p, (size_t)f->cols, (size_t)f->cols, f->rows, hipMemcpyDeviceToHost, ctx->stream));
+    ASW_HIP_TRY(copy_rows(ctx, disp_u8->data, disp_u8->step, u8.p, (size_t)f->cols, (size_t)f->cols, f->rows, hipMemcpyDeviceToHost));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
 }
@@ -355,8 +370,7 @@ int download_disparity_from(asw_ctx* ctx, Frame* f, asw_image* disp)
     if (!f || !f->valid || !f->has_disp || !f->disp.p || f->disp_rows != f->rows || f->disp_cols != f->cols) return ASW_ERR_NO_FRAME;
     ASW_TRY(check_disp_out(disp, f->rows, f->cols));
     ASW_HIP_TRY(hipSetDevice(ctx->device));
-    ASW_HIP_TRY(copy_rows(disp->data, disp->step, f->disp.p, (size_t)f->cols * 4, (size_t)f->cols * 4, f->rows, hipMemcpyDeviceToHost,
-                          ctx->stream));
+    ASW_HIP_TRY(copy_rows(ctx, disp->data, disp->step, f->disp.p, (size_t)f->cols * 4, (size_t)f->cols * 4, f->rows, hipMemcpyDeviceToHost));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ASW_OK;
 }

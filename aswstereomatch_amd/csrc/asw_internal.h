@@ -63,6 +63,7 @@ struct asw_ctx {
     hipStream_t stream = nullptr;
     std::vector<Frame> frames;  // resident slots of asw_upload_pair / asw_match_resident (caller-numbered)
     Frame host_frame;           // private frame of the host-buffer entry points (asw_stereo_match, asw_aggregate_*): never a slot
+    std::vector<unsigned char> host_pack;  // dense staging for host images whose rows carry padding (asw_context.hip: copy_rows)
     std::map<std::string, DevBuf> scratch;  // named grow-only scratch buffers
     BilateralTables bil;
     // weighted-median tables: exp() LUT of the colour weight per rateR, space kernel per (win, rateS)

@@ -318,3 +318,29 @@ def test_short_cost_volume_buffer_is_refused(ctx):
     assert rc == asw.ERR_BAD_ARGUMENT and (guard == 7.0).all()
     rc = ctx._lib.asw_stereo_match(ctx._h, C.byref(li), C.byref(ri), C.byref(di), 0, 2, 5, 0, 4, pv, 5 * 12 * 20)
     assert rc == 0 and (guard[5 * 12 * 20:] == 7.0).all() and not (guard[:5 * 12 * 20] == 7.0).all()
+
+
+def test_padded_host_rows_in_and_out(ctx, oracle):
+    # asw_image.step > cols * channels on every host buffer (a cv::Mat ROI): rows are packed / unpacked on the host and travel as
+    # one dense copy (asw_context.hip: copy_rows); widths whose rows are no multiple of 64 bytes are the case that matters
+    import ctypes as C
+    from aswstereomatch_amd import _image
+    H, W = 9, 131
+    L, R, _ = make_pair(H, W, 6, seed=321, block=8)
+    Lp = np.full((H, W + 5, 3), 7, np.uint8)
+    Rp = np.full((H, W + 9, 3), 200, np.uint8)
+    Lp[:, :W], Rp[:, :W] = L, R
+    want = oracle.asw_classic(L, R, 30, 20, 0, 7, 0, 6)[1]
+    got = ctx.stereoMatching(Lp[:, :W], Rp[:, :W], LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 6)   # padded inputs, dense output
+    assert np.array_equal(got, want)
+    ctx.upload_pair(3, Lp[:, :W], Rp[:, :W])
+    ctx.match_resident(3, LEFT, A.ADAPTIVE_WEIGHT, 7, 0, 6, keep_volume=False)
+    big = np.full((H, W + 3), -5.0, np.float32)
+    di, _keep = _image(big[:, :W], 5)                      # padded float output
+    assert di.step == (W + 3) * 4
+    assert ctx._lib.asw_download_disparity(ctx._h, 3, C.byref(di)) == 0
+    assert np.array_equal(big[:, :W], want) and (big[:, W:] == -5.0).all()
+    u8big = np.full((H, W + 2), 9, np.uint8)
+    ui, _keep2 = _image(u8big[:, :W])
+    assert ctx._lib.asw_download_disparity_u8(ctx._h, 3, C.byref(ui), 0) == 0
+    assert np.array_equal(u8big[:, :W], oracle.disparity_to_u8(want, False)) and (u8big[:, W:] == 9).all()
