@@ -88,10 +88,22 @@ def _image(arr, depth=0):
 class Context:
     """One device context (asw_create / asw_destroy).  Not shared between threads."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, env=None):
+        """env: measurement / test switches (ASW_BILATERAL_XQ, ASW_BAND_Q, ...) for THIS context: the library reads its
+        switches once, inside asw_create, so they are set only around that call."""
         self._h = C.c_void_p()
         self._lib = _lib.lib()
-        rc = self._lib.asw_create(int(device_id), C.byref(self._h))
+        saved = {k: os.environ.get(k) for k in (env or {})}
+        try:
+            for k, v in (env or {}).items():
+                os.environ[k] = str(v)
+            rc = self._lib.asw_create(int(device_id), C.byref(self._h))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if rc != 0:
             raise AswError(rc, "asw_create(device %d)" % device_id)
         self.device_id = device_id

@@ -412,6 +412,7 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     a.gscales = gsc.as<float2>(); a.P = raw.as<float>(); a.pscales = psc.as<float2>();
     a.H = H; a.W = W; a.n = 1; a.r = r; a.minD = 0; a.eps = eps;
     a.stats = stats.as<float>(); a.rep_scratch = nullptr; a.ab = ab.as<float>(); a.q = qv.as<float>();
+    a.tune = &ctx->tune;
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_HIP_TRY(hipMemcpyAsync(q, qv.p, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
     ASW_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -68,6 +68,21 @@ extern "C" int asw_device_count(void)
     return n;
 }
 
+void AswTuning::read_environment()
+{
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; };
+    bilateral_xq = num("ASW_BILATERAL_XQ", bilateral_xq);
+    geodesic_xq = num("ASW_GEODESIC_XQ", geodesic_xq);
+    wmedian_tile = num("ASW_WMEDIAN_TILE", wmedian_tile);
+    wmedian_tile_chunk = num("ASW_WMEDIAN_TILE_CHUNK", wmedian_tile_chunk);
+    wmedian_tile_split = num("ASW_WMEDIAN_TILE_SPLIT", wmedian_tile_split);
+    band_ab = num("ASW_BAND_AB", band_ab);
+    band_q = num("ASW_BAND_Q", band_q);
+    ring_ab = num("ASW_RING_AB", ring_ab);
+    ring_q = num("ASW_RING_Q", ring_q);
+    q_wg_strips = num("ASW_Q_WG_STRIPS", q_wg_strips);
+}
+
 extern "C" int asw_create(int device_id, asw_ctx** out)
 {
     if (!out) return ASW_ERR_BAD_ARGUMENT;
@@ -78,6 +93,7 @@ extern "C" int asw_create(int device_id, asw_ctx** out)
     ASW_HIP_TRY(hipSetDevice(device_id));
     asw_ctx* c = new asw_ctx();
     c->device = device_id;
+    c->tune.read_environment();  // the only place the library reads its switches
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ASW_ERR_HIP;

@@ -56,8 +56,23 @@ struct BilateralTables {  // cached per (kind, win, gamma_c, gamma_g, mirror)
     DevBuf cells; // kind 0, win 15, not mirrored: int4 per window cell (kx = -3..17, ky = 0..14) for k_asw_bilateral_xq
 };
 
+// Measurement / test switches, read from the environment ONCE when a context is created (asw_create): a call never looks at
+// the environment.  -1 / 0 = the library's own choice.
+struct AswTuning {
+    int bilateral_xq = -1;       // ASW_BILATERAL_XQ: 0 = one-kernel form only (k_asw_bilateral), 1 = xq form wherever it applies
+    int geodesic_xq = -1;        // ASW_GEODESIC_XQ
+    int wmedian_tile = -1;       // ASW_WMEDIAN_TILE: 0 = per-pixel sort (k_wmedian)
+    int wmedian_tile_chunk = 0;  // ASW_WMEDIAN_TILE_CHUNK: slices per list chunk (tests: odd chunkings)
+    int wmedian_tile_split = 0;  // ASW_WMEDIAN_TILE_SPLIT: workgroups per pixel block
+    int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
+    int ring_ab = 1, ring_q = 2; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_ab_q3), 0 = re-fetch
+    int q_wg_strips = 0;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
+    void read_environment();
+};
+
 struct asw_ctx {
     int device = 0;
+    AswTuning tune;
     int prep_ntaps = 0;  // taps of the pre-processing bilateral filter (tables in buf("prep_tables"))
     int gray_bits = 14;  // cvtColor(BGR2GRAY) constant set (asw_set_gray_bits): 14 = OpenCV 4.1.0, 15 = later 4.x
     hipStream_t stream = nullptr;
@@ -175,6 +190,7 @@ struct GuidedLaunch {
     int* rep_scratch;       // scratch, n ints (or null): scale-group representative of every slice (6-channel per-slice guides)
     float* ab;              // scratch, guided_ab_floats(): {a_c, b} interleaved per pixel
     float* q;               // out [n][H][W]
+    const AswTuning* tune;  // the context's switches
 };
 size_t guided_stats_floats(int C, int nstat, int H, int W);
 size_t guided_ab_floats(int C, int n, int H, int W);
@@ -202,7 +218,7 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
                    int max_off, float* out);
 size_t wmedian_tile_list_slots(int H, int W, int d_count);
 int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int numD, int max_off,
-                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out);
+                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int nsplit /* A/B: AswTuning */);
 
 // ---- O(1)-bilateral ASW (BLO1), k_blo1.hip ----
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,

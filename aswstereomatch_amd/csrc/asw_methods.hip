@@ -147,10 +147,9 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     // first 128 candidates and this kernel for the tail.  The tile of the outermost workgroup must still hold the eight image
     // columns next to the border its positions clamp to: LEFT minD <= 48 (columns 0..7 in the first tile), RIGHT
     // x0_last + minD <= W - 1 (columns W-8..W-1 in the last).  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B, tests).
-    const char* xq_env = getenv("ASW_BILATERAL_XQ");
     const bool xq_fits = flip ? (W - 1) / 64 * 64 + mp.minD <= W - 1 : mp.minD <= 48;
     const bool use_xq = !direct8 && mp.win == 15 && nD >= bilateral_xq_candidates() && mp.minD >= 0 && xq_fits && W >= 64 &&
-                        !(xq_env && xq_env[0] == '0');
+                        ctx->tune.bilateral_xq != 0;
     if (use_xq) {
         DevBuf& pe = ctx->buf("bil_partE");
         DevBuf& pd = ctx->buf("bil_partD");
@@ -378,6 +377,7 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     DevBuf& repb = ctx->buf("g_rep");
     ASW_TRY(repb.ensure((size_t)n * sizeof(int)));
     a.stats = stats.as<float>(); a.rep_scratch = repb.as<int>(); a.ab = ab.as<float>(); a.q = f->vol.as<float>();
+    a.tune = &ctx->tune;
     ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
@@ -429,8 +429,7 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
     // Long candidate ranges of the 15x15 case (either direction) run as passes of the xq kernel (128 / 64 candidates each) plus
     // k_asw_geodesic for what is left (< 64 candidates); every pass leaves its winners in one slice, merged at the end with
     // the reference's strict '<' in ascending d.  ASW_GEODESIC_XQ=0 forces the one-kernel path.
-    const char* gxq_env = getenv("ASW_GEODESIC_XQ");
-    if (mp.win == 15 && nD >= geodesic_xq_pass_candidates(4) && W >= 64 && mp.minD >= 0 && !(gxq_env && gxq_env[0] == '0')) {
+    if (mp.win == 15 && nD >= geodesic_xq_pass_candidates(4) && W >= 64 && mp.minD >= 0 && ctx->tune.geodesic_xq != 0) {
         // fixed image (the one the disparity map belongs to) / other image
         const uint32_t* pf = flip ? pr.as<uint32_t>() : pl.as<uint32_t>();
         const uint32_t* po = flip ? pl.as<uint32_t>() : pr.as<uint32_t>();
@@ -545,18 +544,18 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     // 15x15 (the reference's call site): the neighbourhood of an 8x8 pixel block is sorted once per slice and every pixel walks
     // it (k_wmedian_tile.hip); other windows sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
     // (3 KB per block and slice) below 2 GiB.  ASW_WMEDIAN_TILE=0 forces the per-pixel sort (A/B measurements, tests).
-    const char* wmt_env = getenv("ASW_WMEDIAN_TILE");
-    if (mp.win == 15 && !(wmt_env && wmt_env[0] == '0')) {
+    if (mp.win == 15 && ctx->tune.wmedian_tile != 0) {
         const size_t per_slice = wmedian_tile_list_slots(H, W, 1);
         int chunk = (int)std::min<size_t>((size_t)n, std::max<size_t>(8, (((size_t)2 << 30) / 6 / per_slice) / 8 * 8));
-        if (const char* ce = getenv("ASW_WMEDIAN_TILE_CHUNK")) chunk = std::max(1, std::min(n, atoi(ce)));  // tests: odd chunkings
+        if (ctx->tune.wmedian_tile_chunk > 0) chunk = std::max(1, std::min(n, ctx->tune.wmedian_tile_chunk));  // tests: odd chunkings
         DevBuf& lc = ctx->buf("wmListC");
         DevBuf& lp = ctx->buf("wmListP");
         ASW_TRY(lc.ensure(per_slice * chunk * 4));
         ASW_TRY(lp.ensure(per_slice * chunk * 2));
         for (int d0 = 0; d0 < n; d0 += chunk)
             ASW_TRY(launch_wmedian_tile(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, n, max_off, d0,
-                                        std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>()));
+                                        std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>(),
+                                        ctx->tune.wmedian_tile_split));
     } else
         ASW_TRY(launch_wmedian(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off,
                                f->vol.as<float>()));

@@ -13,6 +13,9 @@
 // The kernels are bound by f64 VALU + HBM streaming of the a/b planes, see DESIGN.md.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "asw_device.h"
 #include "asw_internal.h"
 
@@ -20,6 +23,7 @@ namespace {
 
 
 constexpr int BW = 256;  // threads per block = 4 independent wavefronts
+struct NoRaw {};
 
 // Every wavefront owns a strip of 128 input columns (two adjacent ones per lane, 128-(k-1) output columns)
 // of a band of rows and walks down the band on its own:
@@ -37,9 +41,18 @@ constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 // KT: the window size when it is known at compile time (15: the reference's call site), 0 = run-time k.  With a run-time k
 // the horizontal sum is a loop of dependent LDS round trips (8 terms, then one per iteration); with KT its 16 doubles per plane
 // are read at once.
-template <int NP, int CPL, int ND, int WPE, bool NANSAFE, int KT, class Src, class Dst>
+// RING (needs KT = 15): the fetched operands of the last KT rows stay in a register ring (Src::KEEP dwords per column and
+// row, 16-entry vectors indexed with the wave-uniform slot s mod KT: s_set_gpr_idx_on / v_mov, the row loop is NOT unrolled),
+// so the leaving row is never fetched again.  Without the ring the q pass of the guided filter fetched 11.5 GB to read 4.05 GB
+// of a/b planes (between a row's first and second fetch the wavefronts of an XCD stream 15 MB through its 4 MB L2), and short
+// bands were needed to keep that re-read in L2 at all; with it a band can be as tall as the launch geometry allows (k-1
+// warm-up rows per band: 44 % of the work at 32 rows, 10 % at 135).
+typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+template <int NP, int CPL, int ND, int WPE, bool NANSAFE, int KT, int RING, int PF, class Src, class Dst>
 __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k_rt, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
 {
+    static_assert(!RING || KT == 15, "the register ring is a 16-entry vector per kept dword");
+    static_assert(PF >= 1 && PF <= 3, "depth of the software pipeline");
     const int k = KT ? KT : k_rt;
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -59,8 +72,11 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     const int spw = slice_par ? 4 : 1;
     const int nzg = ((nslices + ND - 1) / ND + spw - 1) / spw;
     const int wj = blockIdx.x >> 3;
-    const int reg = (wj / nzg) * 8 + (blockIdx.x & 7);
-    if (reg >= ngx * nby) return;
+    // an XCD takes a contiguous run of regions: the regions it has in flight at any time are neighbouring strips of one band,
+    // whose halo columns (and the 128-byte lines two strips share) are then fetched from HBM once
+    const int rpx = (ngx * nby + 7) >> 3;
+    const int reg = (blockIdx.x & 7) * rpx + wj / nzg;
+    if (wj / nzg >= rpx || reg >= ngx * nby) return;
     const int gx = reg % ngx, by = reg / ngx;
     const int xw = slice_par ? gx : gx * 4 + wv;              // wavefront's strip index
     const int zg = slice_par ? (wj % nzg) * 4 + wv : wj % nzg;  // wavefront's slice group
@@ -105,28 +121,92 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 #pragma unroll
             for (int p = 0; p < NP; p++) vs[c][n][p] = 0.0;
 
+    constexpr int NK = RING ? Src::KEEP : 1;
+    v16u ring[CPL][ND][NK];
+    if constexpr (RING) {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int n = 0; n < ND; n++)
+#pragma unroll
+                for (int j = 0; j < NK; j++) ring[c][n][j] = 0;
+    }
+    int slot = 0;  // s mod k, wave-uniform
     const int steps = (y1 - y0) + k - 1;
-    for (int s = 0; s < steps; s++) {
-        const int yn = reflect101_idx(y0 - hl + s, H);
+
+    // One step = one input row.  The walk is three straight-line loops (warm-up: accumulate only; the first output row: nothing
+    // leaves yet; steady state) instead of one loop full of `s >= k` branches: around a conditional load the compiler puts the
+    // wait for it right behind the load (a full memory round trip, twice per step), and nothing moves across the branches.
+    // Software pipeline of depth PF: EVERY load of step s -- entering row, what the leaving row still needs from memory, the
+    // consumer's operands of the output row -- is issued at the top of step s-PF into a register FIFO of PF+1 slots (the step
+    // body exists once per slot: the slot index is a compile-time phase).  Two reasons: (i) memory-level parallelism -- a
+    // wavefront with one row in flight at 2-3 wavefronts per SIMD keeps ~20 KB per CU in flight, short of what 5 TB/s need;
+    // (ii) vmcnt counts loads and stores in issue order on gfx9, so a load issued after the previous step's stores cannot be
+    // waited for without waiting for those stores as well; issued a step earlier, every wait names only older loads.
+    constexpr int NPH = PF + 1;
+    typename Src::Raw fN[NPH][CPL][ND];
+    using LeaveT = typename std::conditional<RING != 0, typename Src::LRaw, typename Src::Raw>::type;  // what the leaving row loads
+    LeaveT fL[NPH][CPL][ND];
+    typename Dst::Raw fD[NPH][CPL][ND];
+    auto issue = [&](int s, auto slot_c) {  // loads of step s into FIFO slot slot_c
+        constexpr int SL = decltype(slot_c)::value;
+        const int yn = reflect101_idx(y0 - hl + s, H);  // steps past the end: valid rows, never used
         const int yo = reflect101_idx(y0 - hl + s - k, H);
         const int yd = min(max(y0 + s - (k - 1), y0), y1 - 1);
-        // ---- all loads of this step, back to back (no store in between: equal addresses merge) ----
-        typename Src::Raw rn[CPL][ND], ro[CPL][ND];
-        typename Dst::Raw rd[CPL][ND];
 #pragma unroll
         for (int c = 0; c < CPL; c++)
 #pragma unroll
             for (int n = 0; n < ND; n++) {
-                rn[c][n] = src.fetch(yn, scol[c][n]);
-                if (s >= k) ro[c][n] = src.fetch(yo, scol[c][n]);
-                if (s >= k - 1) rd[c][n] = dst.fetch(yd, dcol[c][n]);
+                fN[SL][c][n] = src.fetch(yn, scol[c][n]);
+                if constexpr (RING) fL[SL][c][n] = src.leave_fetch(yo, scol[c][n]);
+                else fL[SL][c][n] = src.fetch(yo, scol[c][n]);
+                fD[SL][c][n] = dst.fetch(yd, dcol[c][n]);
             }
+    };
+    if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
+    if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
+    if constexpr (PF >= 3) issue(2, std::integral_constant<int, 2>());
+
+    auto step = [&](int s, auto ph_c, auto sub_c, auto out_c) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr bool SUB = decltype(sub_c)::value, OUT = decltype(out_c)::value;
+        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
+        typename Src::Raw (&rn)[CPL][ND] = fN[PH];
+        typename Dst::Raw (&rd)[CPL][ND] = fD[PH];
+        typename Src::Raw ro[CPL][ND];
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int n = 0; n < ND; n++) {
+                if constexpr (SUB) {
+                    if constexpr (RING) {
+                        uint32_t w[NK];
+#pragma unroll
+                        for (int j = 0; j < NK; j++) w[j] = ring[c][n][j][slot];
+                        ro[c][n] = src.leave(w, fL[PH][c][n]);
+                    } else {
+                        ro[c][n] = fL[PH][c][n];
+                    }
+                }
+            }
+        if constexpr (RING) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (int n = 0; n < ND; n++) {
+                    uint32_t w[NK];
+                    src.keep(rn[c][n], w);
+#pragma unroll
+                    for (int j = 0; j < NK; j++) ring[c][n][j][slot] = w[j];
+                }
+            slot = slot + 1 == k ? 0 : slot + 1;
+        }
         // ---- vertical running sums (ColumnSum: SUM -= leaving row, SUM += entering row) ----
 #pragma unroll
         for (int c = 0; c < CPL; c++)
 #pragma unroll
             for (int n = 0; n < ND; n++) {
-                if (s >= k) {
+                if constexpr (SUB) {
                     float o[NP];
                     src.eval(ro[c][n], scol[c][n], o);
 #pragma unroll
@@ -136,11 +216,11 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                 src.eval(rn[c][n], scol[c][n], v);
 #pragma unroll
                 for (int p = 0; p < NP; p++) vs[c][n][p] = vs[c][n][p] + (double)v[p];
-                if constexpr (NANSAFE) {
+                if constexpr (NANSAFE && OUT) {
                     bool poisoned = false;
 #pragma unroll
                     for (int p = 0; p < NP; p++) poisoned = poisoned || !__builtin_isfinite(vs[c][n][p]);
-                    if (poisoned && s >= k - 1) {  // rebuild the window sum of rows s-k+1 .. s (ascending)
+                    if (poisoned) {  // rebuild the window sum of rows s-k+1 .. s (ascending)
                         double acc[NP];
 #pragma unroll
                         for (int p = 0; p < NP; p++) acc[p] = 0.0;
@@ -156,14 +236,21 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                     }
                 }
             }
-        if (s >= k - 1) {
+        if constexpr (OUT) {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
 #pragma unroll
                 for (int n = 0; n < ND; n++)
 #pragma unroll
                     for (int p = 0; p < NP; p++) hs[(n * NP + p) * (SW + 2) + c0 + c] = vs[c][n][p];
-            // same-wavefront LDS traffic is ordered: the reads below see the writes above
+            // Same-wavefront LDS traffic is ordered in hardware: the reads below see the writes above without a workgroup
+            // barrier.  The COMPILER must be told that other lanes read these words: to a single thread its own store
+            // (offset c0) and its loads (offsets c0+1 ..) never alias, and LLVM promotes the stored value to a register and
+            // sinks the store out of the row loop (seen with the straight-line walk: every row after the first was wrong).
+            // Wavefront-scope fences cost no instruction.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (any_out) {
                 const int y = y0 + s - (k - 1);
 #pragma unroll
@@ -206,8 +293,27 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                     }
                 }
             }
+            // the next row's stores stay behind this row's loads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-    }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0, ph = 0;
+    auto run = [&](int s_end, auto sub_c, auto out_c) {
+        for (; s < s_end; s++) {
+            if (ph == 0) step(s, std::integral_constant<int, 0>(), sub_c, out_c);
+            if constexpr (NPH > 1) { if (ph == 1) step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); }
+            if constexpr (NPH > 2) { if (ph == 2) step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); }
+            if constexpr (NPH > 3) { if (ph == 3) step(s, std::integral_constant<int, 3 % NPH>(), sub_c, out_c); }
+            ph = ph + 1 == NPH ? 0 : ph + 1;
+        }
+    };
+    run(min(k - 1, steps), F(), F());
+    run(min(k, steps), F(), T());
+    run(steps, T(), T());
 }
 
 // ---- guide access: normalised guide channels I_c(y,x) for slice k --------------------------------
@@ -257,7 +363,6 @@ struct GuideAccT {
     }
 };
 
-struct NoRaw {};
 
 // Guide statistics, interleaved per pixel and per BGRX word: {meanI_0..2, den_0..2, pad, pad} = 8 floats, two dwordx4
 // loads for the consumer.  A 3-channel guide has one such array [slot][H][W][8]; a 6-channel guide has one per word plus,
@@ -299,6 +404,21 @@ struct StatsSrc {
     {
         Raw r;
         g.template fetch<C / 3>(y, c, r.u);
+        return r;
+    }
+    static constexpr int KEEP = C / 3;
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[KEEP]) const
+    {
+#pragma unroll
+        for (int i = 0; i < KEEP; i++) w[i] = r.u[i];
+    }
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[KEEP], const LRaw&) const
+    {
+        Raw r;
+#pragma unroll
+        for (int i = 0; i < KEEP; i++) r.u[i] = w[i];
         return r;
     }
     __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&v)[6]) const
@@ -361,9 +481,12 @@ __global__ void k_scale_groups(const float2* __restrict__ scales, int n, int* __
 template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
 
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
-template <int C, bool SHIFT>
+// KEEPG: the register ring keeps the guide word(s) next to the cost (C/3 + 1 dwords per column and row); otherwise the cost
+// only, and the guide pixel of the leaving row is fetched again (slice-independent: an L1 / L2 hit)
+template <int C, bool SHIFT, bool KEEPG = true>
 struct ABSrc {
     static const char* band_env() { return "ASW_BAND_AB"; }
+    static constexpr int KEEP = KEEPG ? C / 3 + 1 : 1;
     GuideAccT<SHIFT> g;
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
@@ -376,6 +499,30 @@ struct ABSrc {
         Raw r;
         g.template fetch<C / 3>(y, c.g, r.u);
         r.p = c.p[(size_t)y * W];
+        return r;
+    }
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[KEEP]) const
+    {
+        w[0] = __float_as_uint(r.p);
+        if constexpr (KEEPG) {
+#pragma unroll
+            for (int i = 0; i < C / 3; i++) w[1 + i] = r.u[i];
+        }
+    }
+    struct LRaw { uint32_t u[KEEPG ? 1 : C / 3]; };  // the guide word(s) of the leaving row when the ring holds the cost only
+    __device__ __forceinline__ LRaw leave_fetch(int yo, const Col& c) const
+    {
+        LRaw l;
+        if constexpr (KEEPG) l.u[0] = 0;
+        else g.template fetch<C / 3>(yo, c.g, l.u);
+        return l;
+    }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[KEEP], const LRaw& l) const
+    {
+        Raw r;
+#pragma unroll
+        for (int i = 0; i < C / 3; i++) r.u[i] = KEEPG ? w[KEEPG ? 1 + i : 0] : l.u[KEEPG ? 0 : i];
+        r.p = __uint_as_float(w[0]);
         return r;
     }
     __device__ __forceinline__ void eval(const Raw& r, const Col& c, float (&v)[C + 1]) const
@@ -478,6 +625,25 @@ struct QSrc {
         for (int i = 0; i < AS / 4; i++) r.v[i] = p[i];
         return r;
     }
+    static constexpr int KEEP = AS;
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[KEEP]) const
+    {
+#pragma unroll
+        for (int i = 0; i < AS / 4; i++) {
+            w[4 * i] = __float_as_uint(r.v[i].x); w[4 * i + 1] = __float_as_uint(r.v[i].y);
+            w[4 * i + 2] = __float_as_uint(r.v[i].z); w[4 * i + 3] = __float_as_uint(r.v[i].w);
+        }
+    }
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[KEEP], const LRaw&) const
+    {
+        Raw r;
+#pragma unroll
+        for (int i = 0; i < AS / 4; i++)
+            r.v[i] = make_float4(__uint_as_float(w[4 * i]), __uint_as_float(w[4 * i + 1]), __uint_as_float(w[4 * i + 2]), __uint_as_float(w[4 * i + 3]));
+        return r;
+    }
     __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[C + 1]) const
     {
         float t[AS];
@@ -535,6 +701,11 @@ struct SadSrc {
         const size_t row = (size_t)y * W;
         return Raw{(int)c.a[row], (int)c.b[row]};
     }
+    static constexpr int KEEP = 1;
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[1]) const { w[0] = (uint32_t)r.a | ((uint32_t)r.b << 8); }
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[1], const LRaw&) const { return Raw{(int)(w[0] & 0xffu), (int)(w[0] >> 8)}; }
     __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[1]) const { v[0] = (float)abs(r.a - r.b); }
 };
 // plain 8U plane as f32 (boxFilter(8U -> CV_32F) of getInputImgNCC, M.cpp:785-786)
@@ -546,6 +717,11 @@ struct U8Src {
     struct Raw { int v; };
     __device__ __forceinline__ Col col(int x, int) const { return Col{img + x}; }
     __device__ __forceinline__ Raw fetch(int y, const Col& c) const { return Raw{(int)c.p[(size_t)y * W]}; }
+    static constexpr int KEEP = 1;
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[1]) const { w[0] = (uint32_t)r.v; }
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[1], const LRaw&) const { return Raw{(int)w[0]}; }
     __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[1]) const { v[0] = (float)r.v; }
 };
 struct PlaneDst {
@@ -558,21 +734,31 @@ struct PlaneDst {
     __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
     __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[1]) const { c.o[(size_t)y * W] = m[0]; }
 };
-template <int NP, int CPL, int ND, int WPE = 4, bool NANSAFE = false, class Src, class Dst>
-int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
+// band: rows per band (0 = default); wg_strips: 1 = the four wavefronts of a workgroup take four neighbouring strips of one slice
+// (they share halo columns in L1), 0 = four slices of one strip (they share the slice-independent operands), -1 = default
+struct WalkOpts { int band = 0; int wg_strips = -1; };
+
+template <int NP, int CPL, int ND, int WPE = 4, bool NANSAFE = false, int RING = 0, int PF = 1, class Src, class Dst>
+int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1, WalkOpts o = WalkOpts())
 {
     constexpr int SW = 64 * CPL;
     if (k < 1 || k > SW / 2) return ASW_ERR_BAD_ARGUMENT;  // k-1 halo columns must leave outputs in the strip
     const int XO = SW - (k - 1);
     const int nxw = (W + XO - 1) / XO;
-    // rows per band: with the XCD-aware order short bands win for the multi-channel passes although every band pays k-1
-    // warm-up rows (1080p D=128 GuidedF_2, a/b + q pass: 16 rows 5.53 ms, 20..32 rows 5.43-5.50, 48 rows 5.79, 64 rows 6.09,
-    // 128 rows 6.24, 270 rows 8.15); the single-channel launches (SAD cost, BLO1) are best at 64
+    const int nzs = (n + ND - 1) / ND;
+    const bool ring = RING && k == 15;
+    // rows per band.  Without the register ring the leaving row is fetched a second time, and with the XCD-aware order short
+    // bands keep that re-read in L2 although every band pays k-1 warm-up rows (1080p D=128 GuidedF_2, a/b + q pass: 16 rows
+    // 5.53 ms, 20..32 rows 5.43-5.50, 48 rows 5.79, 64 rows 6.09, 128 rows 6.24, 270 rows 8.15); the single-channel launches
+    // (SAD cost, BLO1) are best at 64.  With the ring nothing is re-read: as few bands as still give the chip ~4 rounds of
+    // wavefronts (4096 resident ones).
     int band = NP >= 4 ? 32 : 64;
-    if (const char* e = getenv(Src::band_env())) {  // measurement hook (tools/sweep_guided_bands.sh): rows per band of this pass
-        const int b = atoi(e);
-        if (b >= 2) band = b;
+    if (ring) {
+        const long long per_band_row = (long long)nxw * nzs;
+        const int nb = (int)std::max(1LL, std::min((long long)H, (16384 + per_band_row - 1) / per_band_row));
+        band = (H + nb - 1) / nb;
     }
+    if (o.band >= 2) band = o.band;  // measurement hook (AswTuning)
     if (band < 2 * k) band = 2 * k;  // keep the warm-up overhead (k-1 rows per band) below ~50 %
     // A launch with too few wavefronts to fill the chip (guide statistics of one slice: 578 at 1080p, 72 at 640x360) is bound by
     // the latency of its serial row walk, not by throughput: shorter bands mean shorter walks and more wavefronts, and the
@@ -582,12 +768,15 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     while (band > 2 && (long long)nxw * ((H + band - 1) / band) * ((n_eff + ND - 1) / ND) < 4096) band /= 2;
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
-    auto kern = k == 15 ? k_box_walk<NP, CPL, ND, WPE, NANSAFE, 15, Src, Dst> : k_box_walk<NP, CPL, ND, WPE, NANSAFE, 0, Src, Dst>;
+    auto kern = ring ? k_box_walk<NP, CPL, ND, WPE, NANSAFE, 15, RING, PF, Src, Dst>
+              : k == 15 ? k_box_walk<NP, CPL, ND, (RING ? 4 : WPE), NANSAFE, 15, 0, 1, Src, Dst>
+                        : k_box_walk<NP, CPL, ND, (RING ? 4 : WPE), NANSAFE, 0, 0, 1, Src, Dst>;
     // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
     // GuidedF_2 -1 %); four strips of the one slice otherwise
-    const int slice_par = (n + ND - 1) / ND >= 4 ? 1 : 0;
+    int slice_par = nzs >= 4 ? 1 : 0;
+    if (o.wg_strips == 1) slice_par = 0;
     const int spw = slice_par ? 4 : 1;
-    const int ngx = slice_par ? nxw : (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = ((n + ND - 1) / ND + spw - 1) / spw;
+    const int ngx = slice_par ? nxw : (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = (nzs + spw - 1) / spw;
     const long long nwg = (long long)((ngx * nby + 7) / 8) * 8 * nzg;  // regions rounded up to a multiple of the 8 XCDs
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby, slice_par);
@@ -596,7 +785,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
 }
 
 template <int NP, int ND = 1, bool NANSAFE = false, class Src, class Dst>
-int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1)
+int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1, WalkOpts o = WalkOpts())
 {
     // Measured on MI355X (1080p D=128): <CPL,prefetch> = <1,0> 6.83 ms, <1,1> 7.11, <2,0> 6.31, <2,1> 6.40 for the NP=4
     // pair of launches; 24.3 / 24.9 / 24.3 / 24.1 ms for NP=7.  The kernels are bound by the memory system
@@ -604,9 +793,36 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     // columns per lane save the shared horizontal sum, ND slices per wavefront share the slice-independent loads.
     // ND > 1 (several slices per wavefront sharing guide pixel and statistics) was measured and rejected: <CPL,ND> =
     // <2,1> 6.2 ms, <2,2> 7.4, <1,2> 7.5, <1,4> 9.7 -- the extra registers cost more occupancy than the traffic saves.
-    return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active);
+    return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active, o);
 }
 
+// the two passes of the 3-channel guided filter (a/b, q) in the forms AswTuning selects
+template <bool SHIFT>
+int launch_ab_q3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>& g, const StatsSplit& sp)
+{
+    const AswTuning& t = *a.tune;
+    int rc;
+    ABDst<3> dst{sp, a.ab, a.H, a.W};
+    WalkOpts oab; oab.band = t.band_ab;
+    WalkOpts oq; oq.band = t.band_q; oq.wg_strips = t.q_wg_strips;
+    const int ring_ab = a.nan_safe ? 0 : t.ring_ab, ring_q = a.nan_safe ? 0 : t.ring_q;
+    if (ring_ab == 1) {  // ring = {cost, guide word}: 2 wavefronts per SIMD
+        ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
+        rc = launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
+    } else if (ring_ab == 2) {  // ring = {cost}, the leaving row's guide word fetched again: 3 wavefronts per SIMD
+        ABSrc<3, SHIFT, false> src{g, a.P, a.pscales, a.H, a.W};
+        rc = launch_walk_t<4, 2, 1, 3, false, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
+    } else {
+        ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
+        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
+    }
+    if (rc != ASW_OK) return rc;
+    QSrc<3> qs{a.ab, a.H, a.W};
+    QDst<3, SHIFT> qd{g, a.q, a.H, a.W};
+    if (ring_q == 1) return launch_walk_t<4, 1, 1, 4, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);  // one column per lane
+    if (ring_q == 2) return launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);  // two: 2 wavefronts per SIMD
+    return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
+}
 
 }  // namespace
 
@@ -644,13 +860,7 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
         rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, 1);
         if (rc != ASW_OK) return rc;
-        ABSrc<3, false> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3> dst{sp, a.ab, a.H, a.W};
-        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
-        if (rc != ASW_OK) return rc;
-        QSrc<3> qs{a.ab, a.H, a.W};
-        QDst<3, false> qd{g, a.q, a.H, a.W};
-        return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
+        return launch_ab_q3<false>(s, a, g, sp);
     }
     GuideAccT<true> g{a.guideA, a.guideB, a.gscales, a.guide_per_slice ? 1 : 0, a.W, a.shiftA, a.shiftB, a.minD};
     if (a.C == 3) {
@@ -658,13 +868,7 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
         rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
         if (rc != ASW_OK) return rc;
-        ABSrc<3, true> src{g, a.P, a.pscales, a.H, a.W};
-        ABDst<3> dst{sp, a.ab, a.H, a.W};
-        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n);
-        if (rc != ASW_OK) return rc;
-        QSrc<3> qs{a.ab, a.H, a.W};
-        QDst<3, true> qd{g, a.q, a.H, a.W};
-        return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n);
+        return launch_ab_q3<true>(s, a, g, sp);
     }
     // 6-channel guide
     const bool share = a.guide_per_slice && a.rep_scratch && ((a.shiftA != 0) != (a.shiftB != 0));

@@ -320,14 +320,13 @@ size_t wmedian_tile_list_slots(int H, int W, int d_count)
 
 // Slices [d_begin, d_begin + d_count) of the 15x15 weighted median; listC: u32[slots], listP: u16[slots].
 int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int numD, int max_off,
-                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out)
+                        int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int nsplit)
 {
     if (d_count <= 0 || d_begin < 0 || d_begin + d_count > numD) return ASW_ERR_BAD_ARGUMENT;
     const int nbx = (W + BW - 1) / BW, nby = (H + BH - 1) / BH;
     hipLaunchKernelGGL(k_wm_sort_regions, dim3((unsigned)(nbx * nby), (unsigned)((d_count + 3) / 4)), dim3(256), 0, s, cost, H, W, nbx,
                        d_begin, d_count, listC, listP);
     // A/B only: 1 | 2 | 4 = parts per block without compaction, 0 (default) = four parts with the compacted lists
-    static const int nsplit = [] { const char* e = getenv("ASW_WMEDIAN_TILE_SPLIT"); return e ? atoi(e) : 0; }();
     const dim3 blk(64 * PICK_WAVES);
     const unsigned nb = (unsigned)(nbx * nby);
     if (nsplit == 1)

@@ -21,12 +21,11 @@ def ctx():
     c.close()
 
 
-def _old_path(fn):
-    os.environ["ASW_BILATERAL_XQ"] = "0"
-    try:
-        return fn()
-    finally:
-        del os.environ["ASW_BILATERAL_XQ"]
+@pytest.fixture(scope="module")
+def ctx_old():
+    c = asw.Context(0, env={"ASW_BILATERAL_XQ": "0"})  # the one-kernel form only (switches are read once, in asw_create)
+    yield c
+    c.close()
 
 
 # (H, W, minD, numD): one and several 64-pixel tiles, partial last tile, the tile whose windows reach the right border,
@@ -36,14 +35,14 @@ SHAPES = [(5, 64, 0, 128), (9, 200, 0, 128), (3, 257, 2, 128), (17, 130, 0, 127)
 
 
 @pytest.mark.parametrize("H,W,minD,numD", SHAPES)
-def test_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD):
+def test_xq_matches_oracle_and_one_kernel_path(ctx, ctx_old, oracle, H, W, minD, numD):
     L, R, _ = make_pair(H, W, min(numD, W // 2), seed=H * 1000 + W, block=16)
     d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, minD, numD, return_cost_volume=True)
     rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 0, 15, minD, numD, want_vol=True)
     assert rc == 0 and v.shape == vw.shape == (numD + 1, H, W)
     assert np.array_equal(v, vw, equal_nan=True), np.argwhere(v != vw)[:5]
     assert np.array_equal(d, dw)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, minD, numD, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, minD, numD, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
@@ -54,25 +53,25 @@ RIGHT_SHAPES = [(5, 64, 0, 128), (9, 200, 0, 128), (3, 257, 0, 128), (17, 130, 1
 
 
 @pytest.mark.parametrize("H,W,minD,numD", RIGHT_SHAPES)
-def test_xq_right_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD):
+def test_xq_right_matches_oracle_and_one_kernel_path(ctx, ctx_old, oracle, H, W, minD, numD):
     L, R, _ = make_pair(H, W, min(numD, W // 2), seed=H * 1000 + W + 7, block=16)
     d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, minD, numD, return_cost_volume=True)
     rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 1, 15, minD, numD, want_vol=True)
     assert rc == 0 and v.shape == vw.shape == (numD + 1, H, W)
     assert np.array_equal(v, vw, equal_nan=True), np.argwhere(v != vw)[:5]
     assert np.array_equal(d, dw)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, minD, numD, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, minD, numD, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
 def test_xq_right_mid_size_and_lr_check(ctx):
     L, R, _ = make_pair(135, 480, 128, seed=15)
     d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
-def test_xq_flat_and_random_images(ctx, oracle):
+def test_xq_flat_and_random_images(ctx, ctx_old, oracle):
     # constant images: all costs 0, every E = 0 -> d = minD everywhere; pure noise: ties and large gray steps
     for L, R in ((np.full((6, 150, 3), 80, np.uint8), np.full((6, 150, 3), 80, np.uint8)),
                  (np.random.default_rng(3).integers(0, 256, (6, 150, 3)).astype(np.uint8),
@@ -82,7 +81,7 @@ def test_xq_flat_and_random_images(ctx, oracle):
         assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw)
 
 
-def test_xq_other_gammas_and_selector(ctx, oracle):
+def test_xq_other_gammas_and_selector(ctx, ctx_old, oracle):
     L, R, _ = make_pair(7, 180, 60, seed=12, block=16)
     for gc, gg in ((30, 2), (7.5, 11.25), (255, 1)):
         d, v = ctx.computeAdaptiveWeight(L, R, gc, gg, LEFT, 15, 0, 130, return_cost_volume=True)
@@ -95,7 +94,7 @@ def test_xq_other_gammas_and_selector(ctx, oracle):
     assert np.array_equal(ctx.download_disparity(5, (7, 180)), oracle.asw_classic(L, R, 30, 20, 0, 15, 0, 128)[1])
 
 
-def test_other_windows_stay_on_the_one_kernel_path(ctx, oracle):
+def test_other_windows_stay_on_the_one_kernel_path(ctx, ctx_old, oracle):
     L, R, _ = make_pair(6, 140, 40, seed=13, block=16)
     for dt, win in ((RIGHT, 13), (LEFT, 13), (LEFT, 17)):
         d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, win, 0, 128, return_cost_volume=True)
@@ -108,5 +107,5 @@ def test_xq_mid_size_equals_one_kernel_path(ctx):
     # is itself checked against the oracle at this size by the fuzz sweeps and at 1080p on row bands)
     L, R, _ = make_pair(270, 480, 128, seed=14)
     d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, 0, 128, return_cost_volume=True)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, 0, 128, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, 0, 128, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)

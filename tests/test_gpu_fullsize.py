@@ -67,11 +67,11 @@ def test_c5_frame_1080p_classic_right_rows_vs_oracle(ctx, oracle):
         rc, dw, vw = oracle.asw_classic(L, R, 30, 20, 1, 15, 0, 128, want_vol=True, rows=rows)
         assert np.array_equal(d[rows[0]:rows[1]], dw[rows[0]:rows[1]])
         assert np.array_equal(v[:, rows[0]:rows[1]], vw[:, rows[0]:rows[1]])
-    os.environ["ASW_BILATERAL_XQ"] = "0"
+    old = asw.Context(0, env={"ASW_BILATERAL_XQ": "0"})
     try:
-        d0, v0 = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
+        d0, v0 = old.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
     finally:
-        del os.environ["ASW_BILATERAL_XQ"]
+        old.close()
     assert np.array_equal(d, d0) and np.array_equal(v, v0, equal_nan=True)
 
 

@@ -20,12 +20,11 @@ def ctx():
     c.close()
 
 
-def _old_path(fn):
-    os.environ["ASW_GEODESIC_XQ"] = "0"
-    try:
-        return fn()
-    finally:
-        del os.environ["ASW_GEODESIC_XQ"]
+@pytest.fixture(scope="module")
+def ctx_old():
+    c = asw.Context(0, env={"ASW_GEODESIC_XQ": "0"})  # the one-kernel form only (switches are read once, in asw_create)
+    yield c
+    c.close()
 
 
 # (H, W, minD, numD): 64 only (one 4-wave pass), 64+tail, 128, 128+64+tail (KITTI's 193 candidates), 2x128, minD > 0,
@@ -36,7 +35,7 @@ SHAPES = [(4, 64, 0, 63), (6, 150, 0, 70), (3, 200, 0, 127), (5, 257, 0, 192), (
 
 @pytest.mark.parametrize("dt", [LEFT, RIGHT])   # M.cpp:1467-1496 / 1498-1520
 @pytest.mark.parametrize("H,W,minD,numD", SHAPES)
-def test_geodesic_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD, numD, dt):
+def test_geodesic_xq_matches_oracle_and_one_kernel_path(ctx, ctx_old, oracle, H, W, minD, numD, dt):
     L, R, _ = make_pair(H, W, min(numD, W // 2), seed=H * 977 + W, block=16)
     if H > 2:
         L[1:3, 20:40] = L[1, 20]   # flat patches: zero weights, 0/0 = NaN slots (App. B-9)
@@ -46,11 +45,11 @@ def test_geodesic_xq_matches_oracle_and_one_kernel_path(ctx, oracle, H, W, minD,
     assert rc == 0 and v.shape == vw.shape == (numD + 1, H, W)
     assert np.array_equal(v, vw, equal_nan=True), np.argwhere(~((v == vw) | (np.isnan(v) & np.isnan(vw))))[:5]
     assert np.array_equal(d, dw)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, minD, numD, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight_geodesic(L, R, dt, 15, minD, numD, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
-def test_geodesic_xq_selector_resident_and_other_cases(ctx, oracle):
+def test_geodesic_xq_selector_resident_and_other_cases(ctx, ctx_old, oracle):
     L, R, _ = make_pair(6, 180, 60, seed=31, block=16)
     assert np.array_equal(ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GEODESIC, 15, 0, 128), oracle.stereo_matching(L, R, 0, 4, 15, 0, 128)[1])
     ctx.upload_pair(6, L, R)
@@ -63,8 +62,8 @@ def test_geodesic_xq_selector_resident_and_other_cases(ctx, oracle):
 
 
 @pytest.mark.parametrize("dt", [LEFT, RIGHT])
-def test_geodesic_xq_mid_size_equals_one_kernel_path(ctx, dt):
+def test_geodesic_xq_mid_size_equals_one_kernel_path(ctx, ctx_old, dt):
     L, R, _ = make_pair(188, 621, 192, seed=32)
     d, v = ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, 0, 192, return_cost_volume=True)
-    d0, v0 = _old_path(lambda: ctx.computeAdaptiveWeight_geodesic(L, R, dt, 15, 0, 192, return_cost_volume=True))
+    d0, v0 = ctx_old.computeAdaptiveWeight_geodesic(L, R, dt, 15, 0, 192, return_cost_volume=True)
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)

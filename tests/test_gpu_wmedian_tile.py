@@ -22,11 +22,12 @@ def ctx():
 
 
 def _with_env(name, value, fn):
-    os.environ[name] = value
+    """fn(context) on a context created under the switch (the library reads its switches once, in asw_create)"""
+    c = asw.Context(0, env={name: value})
     try:
-        return fn()
+        return fn(c)
     finally:
-        del os.environ[name]
+        c.close()
 
 
 # (H, W, minD, numD): blocks cut by the right / bottom image border, images smaller than one region (reflections of
@@ -37,8 +38,8 @@ SHAPES = [(8, 8, 0, 8), (9, 17, 0, 5), (16, 40, 1, 9), (23, 61, 0, 13), (1, 30, 
 @pytest.mark.parametrize("H,W,minD,numD", SHAPES)
 def test_tile_form_matches_oracle_and_per_pixel_sort(ctx, oracle, H, W, minD, numD):
     L, R, _ = make_pair(H, W, max(2, min(numD, W) // 2), seed=H * 131 + W, block=8)
-    run = lambda: ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, minD, numD, return_cost_volume=True)
-    d, v = run()
+    run = lambda c: c.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, minD, numD, return_cost_volume=True)
+    d, v = run(ctx)
     rc, dw, vw = oracle.asw_wmedian(L, R, 0, 15, 10, 10, minD, numD, want_vol=True)
     assert rc == 0 and v.shape == vw.shape == (numD, H, W)
     assert np.array_equal(v, vw), np.argwhere(v != vw)[:5]
@@ -65,7 +66,7 @@ def test_tile_form_slice_chunks(ctx, oracle):
     rc, dw, vw = oracle.asw_wmedian(L, R, 0, 15, 10, 10, 0, 21, want_vol=True)
     for chunk in ("1", "3", "8", "16", "100"):
         d, v = _with_env("ASW_WMEDIAN_TILE_CHUNK", chunk,
-                         lambda: ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, 0, 21, return_cost_volume=True))
+                         lambda c: c.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, 0, 21, return_cost_volume=True))
         assert np.array_equal(v, vw) and np.array_equal(d, dw), chunk
 
 
@@ -74,7 +75,7 @@ def test_tile_form_selector_and_mid_size(ctx, oracle):
     assert np.array_equal(ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_MEDIAN, 15, 0, 24), oracle.stereo_matching(L, R, 0, 10, 15, 0, 24)[1])
     # 188 x 621, D = 64: the two GPU forms check each other (the oracle needs ~10 s for it; the whole-frame C4 test has it)
     L, R, _ = make_pair(188, 621, 64, seed=6)
-    run = lambda: ctx.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, 0, 64, return_cost_volume=True)
-    d, v = run()
+    run = lambda c: c.computeAdaptiveWeight_WeightedMedian(L, R, LEFT, 15, 10, 10, 0, 64, return_cost_volume=True)
+    d, v = run(ctx)
     d0, v0 = _with_env("ASW_WMEDIAN_TILE", "0", run)
     assert np.array_equal(v, v0) and np.array_equal(d, d0)

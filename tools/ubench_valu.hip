@@ -97,6 +97,29 @@ KERNEL(k_bfe_u32, unsigned a0 = threadIdx.x; unsigned a1 = a0 + 1; unsigned a2 =
                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));,
        out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3))
 
+// ONE dependent chain per wave (every instruction reads the previous result): exposes the result latency that the 4-chain
+// kernels above hide
+KERNEL(k_add_f64_dep, double a0 = threadIdx.x; double b = 1.0001;,
+       asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                    "v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                    : "+v"(a0) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = (float)a0)
+KERNEL(k_add_f64_dep2, double a0 = threadIdx.x; double a1 = a0 + 1; double b = 1.0001;,
+       asm volatile("v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n"
+                    "v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n"
+                    : "+v"(a0), "+v"(a1) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1))
+KERNEL(k_add_f32_dep, float a0 = threadIdx.x; float b = 1.0001f;,
+       asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                    "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                    : "+v"(a0) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = a0)
+KERNEL(k_cvt_add_dep, double a0 = threadIdx.x; double t = 0; float b = 1.0001f;,
+       asm volatile("v_cvt_f64_f32 %1, %2\n v_add_f64 %0, %0, %1\n v_cvt_f64_f32 %1, %2\n v_add_f64 %0, %0, %1\n"
+                    "v_cvt_f64_f32 %1, %2\n v_add_f64 %0, %0, %1\n v_cvt_f64_f32 %1, %2\n v_add_f64 %0, %0, %1\n"
+                    : "+v"(a0), "+v"(t) : "v"(b));,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = (float)a0)
+
 typedef void (*kern_t)(float*, int);
 
 int main()
@@ -106,11 +129,13 @@ int main()
     struct { const char* name; kern_t k; } ks[] = {
         {"v_fma_f32", k_fma_f32}, {"v_mul_f32", k_mul_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_bfe_u32", k_bfe_u32},
         {"v_cvt_f32_ubyteN (x1.5)", k_cvt_f32_ubyte}, {"v_cvt_f32_ubyteN", k_cvt_ubyte8}, {"v_and/lshrrev_b32", k_and_shift}, {"v_min/max_u32", k_minmax_u32}, {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64},
-        {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f64_u32", k_cvt_f64_u32}};
+        {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f64_u32", k_cvt_f64_u32},
+        {"v_add_f64 1 chain", k_add_f64_dep}, {"v_add_f64 2 chains", k_add_f64_dep2}, {"v_add_f32 1 chain", k_add_f32_dep},
+        {"cvt_f64_f32+add_f64 chain", k_cvt_add_dep}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int wavesPerSimd : {1, 2, 4}) {
+    for (int wavesPerSimd : {1, 2, 3, 4}) {
         int blocks = 256 * wavesPerSimd;  // 256-thread blocks: 4 waves each -> wavesPerSimd waves per SIMD
         printf("--- %d wave(s) per SIMD (grid %d x 256)\n", wavesPerSimd, blocks);
         for (auto& k : ks) {
