@@ -396,7 +396,7 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     ASW_TRY(psc.ensure(sizeof(float2)));
     ASW_TRY(gsc.ensure(sizeof(float2)));
     ASW_TRY(stats.ensure(guided_stats_floats(C, 1, H, W) * 4));
-    ASW_TRY(ab.ensure(guided_ab_floats(C, 1, H, W) * 4));
+    ASW_TRY(ab.ensure(guided_ab_floats(C, 1, H, W, r) * 4));
     ASW_TRY(qv.ensure(plane * 4));
     ASW_TRY(pxa.ensure(plane * 4));
     ASW_TRY(pxb.ensure(plane * 4));

@@ -65,8 +65,8 @@ struct AswTuning {
     int wmedian_tile_chunk = 0;  // ASW_WMEDIAN_TILE_CHUNK: slices per list chunk (tests: odd chunkings)
     int wmedian_tile_split = 0;  // ASW_WMEDIAN_TILE_SPLIT: workgroups per pixel block
     int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
-    int ring_ab = 1, ring_q = 2; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_ab_q3), 0 = re-fetch
-    int q_wg_strips = 0;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
+    int ring_ab = 1, ring_q = 1; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_guided3), 0 = re-fetch
+    int q_wg_strips = 1;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
     void read_environment();
 };
 
@@ -188,12 +188,12 @@ struct GuidedLaunch {
     int nan_safe;           // 1: P may hold NaN (NCC costs of flat windows; caller-supplied P): window sums are rebuilt when a running sum is poisoned
     float* stats;           // scratch, guided_stats_floats(): {meanI_c, var_c+eps} interleaved per pixel and BGRX word
     int* rep_scratch;       // scratch, n ints (or null): scale-group representative of every slice (6-channel per-slice guides)
-    float* ab;              // scratch, guided_ab_floats(): {a_c, b} interleaved per pixel
+    float* ab;              // scratch, guided_ab_floats(): {a_c, b} per pixel (3-channel guide: strip-major float2 tiles, k_guided.hip ABTiles)
     float* q;               // out [n][H][W]
     const AswTuning* tune;  // the context's switches
 };
 size_t guided_stats_floats(int C, int nstat, int H, int W);
-size_t guided_ab_floats(int C, int n, int H, int W);
+size_t guided_ab_floats(int C, int n, int H, int W, int r);
 int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, int w, uint32_t* out);
 int launch_guided(hipStream_t s, const GuidedLaunch& a);
 

@@ -24,6 +24,8 @@ namespace {
 
 constexpr int BW = 256;  // threads per block = 4 independent wavefronts
 struct NoRaw {};
+template <class D, bool P> struct DstRawSel { using type = typename D::Raw; };
+template <class D> struct DstRawSel<D, true> { using type = typename D::Raw2; };
 
 // Every wavefront owns a strip of 128 input columns (two adjacent ones per lane, 128-(k-1) output columns)
 // of a band of rows and walks down the band on its own:
@@ -52,7 +54,7 @@ template <int NP, int CPL, int ND, int WPE, bool NANSAFE, int KT, int RING, int 
 __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_box_walk(Src src, Dst dst, int H, int W, int k_rt, int band, int nxw, int nslices, int ngx, int nby, int slice_par)
 {
     static_assert(!RING || KT == 15, "the register ring is a 16-entry vector per kept dword");
-    static_assert(PF >= 1 && PF <= 3, "depth of the software pipeline");
+    static_assert(PF >= 0 && PF <= 3, "depth of the software pipeline (0: the loads of a step are issued at its own top)");
     const int k = KT ? KT : k_rt;
     constexpr int SW = 64 * CPL;  // strip width (input columns per wavefront)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -69,17 +71,17 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     // The four wavefronts of a workgroup take four strips of one slice group, or (slice_par) one strip of four
     // consecutive slice groups: they then walk the same rows at the same time and the slice-independent loads of three
     // of them hit in the CU's L1.
-    const int spw = slice_par ? 4 : 1;
+    const int spw = (slice_par & 1) ? 4 : 1;
     const int nzg = ((nslices + ND - 1) / ND + spw - 1) / spw;
     const int wj = blockIdx.x >> 3;
     // an XCD takes a contiguous run of regions: the regions it has in flight at any time are neighbouring strips of one band,
     // whose halo columns (and the 128-byte lines two strips share) are then fetched from HBM once
     const int rpx = (ngx * nby + 7) >> 3;
-    const int reg = (blockIdx.x & 7) * rpx + wj / nzg;
+    const int reg = (slice_par & 2) ? (wj / nzg) * 8 + (blockIdx.x & 7) : (blockIdx.x & 7) * rpx + wj / nzg;
     if (wj / nzg >= rpx || reg >= ngx * nby) return;
     const int gx = reg % ngx, by = reg / ngx;
-    const int xw = slice_par ? gx : gx * 4 + wv;              // wavefront's strip index
-    const int zg = slice_par ? (wj % nzg) * 4 + wv : wj % nzg;  // wavefront's slice group
+    const int xw = (slice_par & 1) ? gx : gx * 4 + wv;              // wavefront's strip index
+    const int zg = (slice_par & 1) ? (wj % nzg) * 4 + wv : wj % nzg;  // wavefront's slice group
     if (xw >= nxw || zg * ND >= nslices) return;              // whole wavefront exits
     const int xo0 = xw * XO;
     const int c0 = CPL * lane;           // first strip column of this lane
@@ -147,7 +149,13 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     typename Src::Raw fN[NPH][CPL][ND];
     using LeaveT = typename std::conditional<RING != 0, typename Src::LRaw, typename Src::Raw>::type;  // what the leaving row loads
     LeaveT fL[NPH][CPL][ND];
-    typename Dst::Raw fD[NPH][CPL][ND];
+    // DPAIR: the consumer fetches the operands of the lane's two adjacent output columns with ONE set of vector loads and stores
+    // both results with one store per plane (planar layouts: every memory instruction of a wavefront covers one dense run).
+    // The L1 handles one 128-byte line per cycle: with per-pixel records (32 B of statistics, 16 B of a/b) and two columns per
+    // lane an instruction touched 16-32 lines, and the a/b pass spent a third of its time in the L1 tag pipeline.
+    constexpr bool DPAIR = CPL == 2 && Dst::PAIR;
+    using DRawT = typename DstRawSel<Dst, DPAIR>::type;
+    DRawT fD[NPH][DPAIR ? 1 : CPL][ND];
     auto issue = [&](int s, auto slot_c) {  // loads of step s into FIFO slot slot_c
         constexpr int SL = decltype(slot_c)::value;
         const int yn = reflect101_idx(y0 - hl + s, H);  // steps past the end: valid rows, never used
@@ -160,7 +168,11 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                 fN[SL][c][n] = src.fetch(yn, scol[c][n]);
                 if constexpr (RING) fL[SL][c][n] = src.leave_fetch(yo, scol[c][n]);
                 else fL[SL][c][n] = src.fetch(yo, scol[c][n]);
-                fD[SL][c][n] = dst.fetch(yd, dcol[c][n]);
+                if constexpr (DPAIR) {
+                    if (c == 0) fD[SL][0][n] = dst.fetch2(yd, dcol[0][n]);
+                } else {
+                    fD[SL][c][n] = dst.fetch(yd, dcol[c][n]);
+                }
             }
     };
     if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
@@ -170,9 +182,9 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     auto step = [&](int s, auto ph_c, auto sub_c, auto out_c) {
         constexpr int PH = decltype(ph_c)::value;
         constexpr bool SUB = decltype(sub_c)::value, OUT = decltype(out_c)::value;
-        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
+        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());  // PF = 0: this step's own loads
         typename Src::Raw (&rn)[CPL][ND] = fN[PH];
-        typename Dst::Raw (&rd)[CPL][ND] = fD[PH];
+        DRawT (&rd)[DPAIR ? 1 : CPL][ND] = fD[PH];
         typename Src::Raw ro[CPL][ND];
 #pragma unroll
         for (int c = 0; c < CPL; c++)
@@ -236,13 +248,24 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                     }
                 }
             }
+        // PAIRS (two adjacent columns per lane, compile-time odd window, finite data): the strip holds {V[2l] + V[2l+1], V[2l]} per
+        // lane instead of {V[2l], V[2l+1]}; with T = the six pair sums of lanes l+1 .. l+6 the two windows are
+        // (pair[l] + T) + V[2(l+7)] and (V[2l+1] + T) + pair[l+7]: 10 f64 additions for the two columns instead of 17, seven
+        // ds_read_b128 instead of eight.  Another association of the same f64 sum (the oracle's: ascending; OpenCV's: sliding).
+        constexpr bool PAIRS = CPL == 2 && KT > 0 && (KT & 1) && !NANSAFE;
         if constexpr (OUT) {
 #pragma unroll
-            for (int c = 0; c < CPL; c++)
+            for (int n = 0; n < ND; n++)
 #pragma unroll
-                for (int n = 0; n < ND; n++)
+                for (int p = 0; p < NP; p++) {
+                    if constexpr (PAIRS) {
+                        hs[(n * NP + p) * (SW + 2) + c0] = vs[0][n][p] + vs[1][n][p];
+                        hs[(n * NP + p) * (SW + 2) + c0 + 1] = vs[0][n][p];
+                    } else {
 #pragma unroll
-                    for (int p = 0; p < NP; p++) hs[(n * NP + p) * (SW + 2) + c0 + c] = vs[c][n][p];
+                        for (int c = 0; c < CPL; c++) hs[(n * NP + p) * (SW + 2) + c0 + c] = vs[c][n][p];
+                    }
+                }
             // Same-wavefront LDS traffic is ordered in hardware: the reads below see the writes above without a workgroup
             // barrier.  The COMPILER must be told that other lanes read these words: to a single thread its own store
             // (offset c0) and its loads (offsets c0+1 ..) never alias, and LLVM promotes the stored value to a register and
@@ -259,6 +282,20 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const double* b = hs + (n * NP + p) * (SW + 2) + c0;
+                        if constexpr (PAIRS) {
+                            constexpr int HP = (KT - 1) / 2;  // whole pairs in a window
+                            double bb[2 * HP + 2];
+#pragma unroll
+                            for (int i = 2; i < 2 * HP + 2; i++) bb[i] = b[i];  // lanes l+1 .. l+HP: {pair, V[even]}
+                            double t = bb[2];
+#pragma unroll
+                            for (int i = 2; i < HP; i++) t = t + bb[2 * i];
+                            const double s0 = ((vs[0][n][p] + vs[1][n][p]) + t) + bb[2 * HP + 1];
+                            const double s1 = (vs[1][n][p] + t) + bb[2 * HP];
+                            m[0][p] = (float)(s0 * scale);
+                            m[1][p] = (float)(s1 * scale);
+                            continue;
+                        }
                         double sum = 0.0, b0, bk = 0.0;
                         if constexpr (KT > 0) {
                             double bb[KT + 1];
@@ -286,9 +323,13 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                         }
                     }
                     if (kvalid[n]) {
-                        dst.emit(y, dcol[0][n], rd[0][n], m[0]);
-                        if constexpr (CPL > 1) {
-                            if (out_col[CPL - 1]) dst.emit(y, dcol[CPL - 1][n], rd[CPL - 1][n], m[CPL - 1]);
+                        if constexpr (DPAIR) {
+                            dst.emit2(y, dcol[0][n], rd[0][n], m[0], m[1], out_col[1]);
+                        } else {
+                            dst.emit(y, dcol[0][n], rd[0][n], m[0]);
+                            if constexpr (CPL > 1) {
+                                if (out_col[CPL - 1]) dst.emit(y, dcol[CPL - 1][n], rd[CPL - 1][n], m[CPL - 1]);
+                            }
                         }
                     }
                 }
@@ -432,6 +473,7 @@ struct StatsSrc {
 // MODE 0: every slice; 1: group representatives only; 2: only the strips that contain border columns of the slice
 template <int MODE>
 struct StatsDst {
+    static constexpr bool PAIR = false;
     float* out;  // [slot][H][W][8]
     StatsSplit sp;
     int H, W;
@@ -537,6 +579,7 @@ struct ABSrc {
 };
 template <int C>
 struct ABDst {
+    static constexpr bool PAIR = false;
     __device__ __forceinline__ bool active(int, int, int) const { return true; }
     StatsSplit sp;
     float* ab;
@@ -655,6 +698,7 @@ struct QSrc {
 };
 template <int C, bool SHIFT>
 struct QDst {
+    static constexpr bool PAIR = false;
     __device__ __forceinline__ bool active(int, int, int) const { return true; }
     GuideAccT<SHIFT> g;
     float* q;  // [n][H][W]
@@ -679,6 +723,247 @@ struct QDst {
             dot = (ch == 0) ? pr : dot + pr;
         }
         c.q[(size_t)y * W] = dot + m[C];
+    }
+};
+
+// ---- planar forms for the 3-channel guide (GuidedF_2, 3-channel getGuidedFilter) ----------------------------------------
+// Statistics: [slot] x { R_0, R_1, R_2 : double [H][W] ; meanI_0..2 : float [H][W] }, R_c = 1 / (double)den_c with
+// den_c = var_c + eps in f32 (M.cpp:2846).  The consumer needs den only as a divisor: a_c = cov_c / den_c =
+// (float)((double)cov_c * R_c) -- three instructions instead of the eleven of an IEEE f32 division (two v_div_scale, v_rcp,
+// five fma/mul, v_div_fmas, v_div_fixup) and the same bits: R_c and the product carry 2^-52 of relative error, and the quotient
+// of two 24-bit numbers is never closer than 2^-49 to a rounding boundary of the 24-bit format (the classical double-precision
+// argument; zero, infinite and NaN divisors behave as in the division; only a subnormal quotient that is an exact tie can round
+// the other way).
+// a/b: [slice] x { {a_0, a_1} ; {a_2, b} } x [strip][H][TW] float2, TW = the output columns of a strip of the a/b pass: STRIP-major,
+// so the rows a wavefront produces are one contiguous stream.  In image order a wavefront stores 912 bytes, then jumps a row
+// pitch (15 KB): measured with the pass's own store pattern (tools/ubench_wpattern.hip), that reaches 3.2 TB/s of HBM write
+// bandwidth against 5.2-5.5 TB/s for contiguous rows -- the 4.25 GB a/b store was 1.3 ms of a 2.6 ms pass.
+// With planes, the two adjacent columns of a lane are one 16-byte (or 8-byte) access per plane and a wavefront's instruction
+// covers one dense run of memory.
+struct ABTiles {
+    int TW;              // columns per strip tile
+    size_t tile;         // H * TW (float2 elements of one strip tile)
+    size_t plane;        // nstrips * tile
+    size_t slice_stride; // 2 * plane, in float2
+    int H;
+    __host__ __device__ size_t col_offset(int x) const { const int t = x / TW; return (size_t)t * tile + (x - t * TW); }
+};
+inline ABTiles ab_tiles(int H, int W, int r)
+{
+    ABTiles a;
+    a.TW = 128 - (r - 1);  // output columns of a two-column-per-lane strip
+    if (a.TW < 2) a.TW = 2;
+    a.H = H;
+    a.tile = (size_t)H * a.TW;
+    a.plane = (size_t)((W + a.TW - 1) / a.TW) * a.tile;
+    a.slice_stride = 2 * a.plane;
+    return a;
+}
+struct StatsPlanes {
+    double* R;   // [slot][3][H][W]
+    float* M;    // [slot][3][H][W]
+    size_t plane;  // H * W
+};
+__host__ __device__ inline StatsPlanes stats_planes(float* base, int nslot, int H, int W)
+{
+    StatsPlanes p;
+    p.plane = (size_t)H * W;
+    p.R = reinterpret_cast<double*>(base);
+    p.M = reinterpret_cast<float*>(p.R + (size_t)nslot * 3 * p.plane);
+    return p;
+}
+struct StatsDstP {
+    static constexpr bool PAIR = true;
+    StatsPlanes sp;
+    int W;
+    float epsf;
+    typedef NoRaw Raw;
+    typedef NoRaw Raw2;
+    struct Col { double* r; float* m; };
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{sp.R + (size_t)k * 3 * sp.plane + x, sp.M + (size_t)k * 3 * sp.plane + x}; }
+    __device__ __forceinline__ Raw fetch(int, const Col&) const { return Raw(); }
+    __device__ __forceinline__ Raw2 fetch2(int, const Col&) const { return Raw2(); }
+    __device__ __forceinline__ void stat(const float (&m)[6], double (&R)[3]) const
+    {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float mm = m[ch] * m[ch];
+            float var = m[3 + ch] - mm;
+            float den = 1.0f * epsf + var;  // scaleAdd(ones, eps, var)
+            R[ch] = 1.0 / (double)den;
+        }
+    }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw&, const float (&m)[6]) const
+    {
+        double R[3];
+        stat(m, R);
+        const size_t row = (size_t)y * W;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { c.r[ch * sp.plane + row] = R[ch]; c.m[ch * sp.plane + row] = m[ch]; }
+    }
+    __device__ __forceinline__ void emit2(int y, const Col& c, const Raw2&, const float (&m0)[6], const float (&m1)[6], bool second) const
+    {
+        double R0[3], R1[3];
+        stat(m0, R0);
+        stat(m1, R1);
+        const size_t row = (size_t)y * W;
+        if (second) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                *reinterpret_cast<double2*>(c.r + ch * sp.plane + row) = make_double2(R0[ch], R1[ch]);
+                *reinterpret_cast<float2*>(c.m + ch * sp.plane + row) = make_float2(m0[ch], m1[ch]);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { c.r[ch * sp.plane + row] = R0[ch]; c.m[ch * sp.plane + row] = m0[ch]; }
+        }
+    }
+};
+// box(P), box(I_c*P) -> a_c, b from the planar statistics, to the planar a/b volume                       (M.cpp:2780-2847)
+struct ABDstP {
+    static constexpr bool PAIR = true;
+    StatsPlanes sp;
+    int per_slice;  // statistics slot = slice (per-slice guide) or 0
+    float2* ab;     // strip-major tiles, see ABTiles
+    ABTiles at;
+    int W;
+    struct Col { const double* r; const float* m; float2* ab; };
+    struct Raw { double R[3]; float mean[3]; };
+    struct Raw2 { double2 R[3]; float2 mean[3]; };
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
+    __device__ __forceinline__ Col col(int x, int k) const
+    {
+        const size_t slot = per_slice ? (size_t)k : 0;
+        return Col{sp.R + slot * 3 * sp.plane + x, sp.M + slot * 3 * sp.plane + x, ab + (size_t)k * at.slice_stride + at.col_offset(x)};
+    }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
+    {
+        Raw r;
+        const size_t row = (size_t)y * W;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { r.R[ch] = c.r[ch * sp.plane + row]; r.mean[ch] = c.m[ch * sp.plane + row]; }
+        return r;
+    }
+    __device__ __forceinline__ Raw2 fetch2(int y, const Col& c) const
+    {
+        Raw2 r;
+        const size_t row = (size_t)y * W;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            r.R[ch] = *reinterpret_cast<const double2*>(c.r + ch * sp.plane + row);
+            r.mean[ch] = *reinterpret_cast<const float2*>(c.m + ch * sp.plane + row);
+        }
+        return r;
+    }
+    __device__ __forceinline__ void ab_of(const double (&R)[3], const float (&mean)[3], const float (&m)[4], float (&o)[4]) const
+    {
+        const float meanP = m[0];
+        float dot = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float mI = mean[ch];
+            float mp = mI * meanP;
+            float cov = m[1 + ch] - mp;
+            float ac = (float)((double)cov * R[ch]);  // == cov / den_c, see above
+            o[ch] = ac;
+            float pr = ac * mI;
+            dot = (ch == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
+        }
+        o[3] = meanP - dot;
+    }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[4]) const
+    {
+        float o[4];
+        ab_of(r.R, r.mean, m, o);
+        const size_t row = (size_t)y * at.TW;
+        c.ab[row] = make_float2(o[0], o[1]);
+        c.ab[at.plane + row] = make_float2(o[2], o[3]);
+    }
+    __device__ __forceinline__ void emit2(int y, const Col& c, const Raw2& r, const float (&m0)[4], const float (&m1)[4], bool second) const
+    {
+        const double Ra[3] = {r.R[0].x, r.R[1].x, r.R[2].x}, Rb[3] = {r.R[0].y, r.R[1].y, r.R[2].y};
+        const float ma[3] = {r.mean[0].x, r.mean[1].x, r.mean[2].x}, mb[3] = {r.mean[0].y, r.mean[1].y, r.mean[2].y};
+        float o0[4], o1[4];
+        ab_of(Ra, ma, m0, o0);
+        ab_of(Rb, mb, m1, o1);
+        const size_t row = (size_t)y * at.TW;
+        if (second) {
+            *reinterpret_cast<float4*>(c.ab + row) = make_float4(o0[0], o0[1], o1[0], o1[1]);
+            *reinterpret_cast<float4*>(c.ab + at.plane + row) = make_float4(o0[2], o0[3], o1[2], o1[3]);
+        } else {
+            c.ab[row] = make_float2(o0[0], o0[1]);
+            c.ab[at.plane + row] = make_float2(o0[2], o0[3]);
+        }
+    }
+};
+// box(a_c), box(b) from the planar a/b volume                                                              (M.cpp:2849-2850)
+struct QSrcP {
+    static const char* band_env() { return "ASW_BAND_Q"; }
+    const float2* ab;  // strip-major tiles, see ABTiles
+    ABTiles at;
+    struct Col { const float2* p; };
+    struct Raw { float2 u, v; };
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{ab + (size_t)k * at.slice_stride + at.col_offset(x)}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const
+    {
+        const size_t row = (size_t)y * at.TW;
+        return Raw{c.p[row], c.p[at.plane + row]};
+    }
+    static constexpr int KEEP = 4;
+    __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[4]) const
+    {
+        w[0] = __float_as_uint(r.u.x); w[1] = __float_as_uint(r.u.y); w[2] = __float_as_uint(r.v.x); w[3] = __float_as_uint(r.v.y);
+    }
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[4], const LRaw&) const
+    {
+        return Raw{make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])), make_float2(__uint_as_float(w[2]), __uint_as_float(w[3]))};
+    }
+    __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[4]) const { v[0] = r.u.x; v[1] = r.u.y; v[2] = r.v.x; v[3] = r.v.y; }
+};
+// q = sum_c box(a_c)*I_c + box(b), slice-independent 3-channel guide: guide pixels and results of the two columns as pairs  (M.cpp:2851-2852)
+struct QDstP {
+    static constexpr bool PAIR = true;
+    GuideAccT<false> g;
+    float* q;  // [n][H][W]
+    int H, W;
+    struct Col { const uint32_t* a; float2 sc; float* q; };
+    struct Raw { uint32_t u; };
+    struct Raw2 { uint2 u; };
+    __device__ __forceinline__ bool active(int, int, int) const { return true; }
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{g.A + x, g.scales[0], q + (size_t)k * H * W + x}; }
+    __device__ __forceinline__ Raw fetch(int y, const Col& c) const { return Raw{c.a[(size_t)y * W]}; }
+    __device__ __forceinline__ Raw2 fetch2(int y, const Col& c) const
+    {
+        const uint32_t* p = c.a + (size_t)y * W;
+        Raw2 r;
+        r.u = make_uint2(p[0], p[1]);  // adjacent dwords: one 8-byte load
+        return r;
+    }
+    __device__ __forceinline__ float q_of(uint32_t u, const Col& c, const float (&m)[4]) const
+    {
+        const float2 sc = c.sc;
+        float I[3];
+        I[0] = (float)(u & 0xffu) * sc.x + sc.y;
+        I[1] = (float)((u >> 8) & 0xffu) * sc.x + sc.y;
+        I[2] = (float)((u >> 16) & 0xffu) * sc.x + sc.y;
+        float dot = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float pr = m[ch] * I[ch];
+            dot = (ch == 0) ? pr : dot + pr;
+        }
+        return dot + m[3];
+    }
+    __device__ __forceinline__ void emit(int y, const Col& c, const Raw& r, const float (&m)[4]) const { c.q[(size_t)y * W] = q_of(r.u, c, m); }
+    __device__ __forceinline__ void emit2(int y, const Col& c, const Raw2& r, const float (&m0)[4], const float (&m1)[4], bool second) const
+    {
+        const float q0 = q_of(r.u.x, c, m0), q1 = q_of(r.u.y, c, m1);
+        float* o = c.q + (size_t)y * W;
+        if (second) *reinterpret_cast<float2*>(o) = make_float2(q0, q1);
+        else o[0] = q0;
     }
 };
 
@@ -725,6 +1010,7 @@ struct U8Src {
     __device__ __forceinline__ void eval(const Raw& r, const Col&, float (&v)[1]) const { v[0] = (float)r.v; }
 };
 struct PlaneDst {
+    static constexpr bool PAIR = false;
     __device__ __forceinline__ bool active(int, int, int) const { return true; }
     float* out;
     int H, W;
@@ -736,7 +1022,7 @@ struct PlaneDst {
 };
 // band: rows per band (0 = default); wg_strips: 1 = the four wavefronts of a workgroup take four neighbouring strips of one slice
 // (they share halo columns in L1), 0 = four slices of one strip (they share the slice-independent operands), -1 = default
-struct WalkOpts { int band = 0; int wg_strips = -1; };
+struct WalkOpts { int band = 0; int wg_strips = -1; int interleave = 0; };
 
 template <int NP, int CPL, int ND, int WPE = 4, bool NANSAFE = false, int RING = 0, int PF = 1, class Src, class Dst>
 int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int k, int n, int n_active = -1, WalkOpts o = WalkOpts())
@@ -769,8 +1055,8 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     size_t lds = (size_t)4 * ND * NP * (SW + 2) * sizeof(double);
     // register target: at least 4 waves/SIMD; asking for 6 or 8 makes the allocator serialise/spill (7.1 / 12.6 ms vs 6.2)
     auto kern = ring ? k_box_walk<NP, CPL, ND, WPE, NANSAFE, 15, RING, PF, Src, Dst>
-              : k == 15 ? k_box_walk<NP, CPL, ND, (RING ? 4 : WPE), NANSAFE, 15, 0, 1, Src, Dst>
-                        : k_box_walk<NP, CPL, ND, (RING ? 4 : WPE), NANSAFE, 0, 0, 1, Src, Dst>;
+              : k == 15 ? k_box_walk<NP, CPL, ND, (RING ? 3 : WPE), NANSAFE, 15, 0, (RING ? 1 : PF), Src, Dst>
+                        : k_box_walk<NP, CPL, ND, (RING ? 3 : WPE), NANSAFE, 0, 0, (RING ? 1 : PF), Src, Dst>;
     // four slices of one strip per workgroup when there are enough slices (1080p D=128: GuidedF 24.1 -> 22.9 ms, BLO1 -7 %,
     // GuidedF_2 -1 %); four strips of the one slice otherwise
     int slice_par = nzs >= 4 ? 1 : 0;
@@ -779,7 +1065,7 @@ int launch_walk_t(hipStream_t s, const Src& src, const Dst& dst, int H, int W, i
     const int ngx = slice_par ? nxw : (nxw + 3) / 4, nby = (H + band - 1) / band, nzg = (nzs + spw - 1) / spw;
     const long long nwg = (long long)((ngx * nby + 7) / 8) * 8 * nzg;  // regions rounded up to a multiple of the 8 XCDs
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby, slice_par);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(BW), lds, s, src, dst, H, W, k, band, nxw, n, ngx, nby, slice_par | ((o.interleave || !ring) ? 2 : 0));
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
@@ -796,32 +1082,49 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active, o);
 }
 
-// the two passes of the 3-channel guided filter (a/b, q) in the forms AswTuning selects
+// the 3-channel guided filter (statistics, a/b, q) on the planar layouts, the two big passes in the forms AswTuning selects
 template <bool SHIFT>
-int launch_ab_q3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>& g, const StatsSplit& sp)
+int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>& g, int nstat)
 {
     const AswTuning& t = *a.tune;
+    const StatsPlanes sp = stats_planes(a.stats, nstat, a.H, a.W);
     int rc;
-    ABDst<3> dst{sp, a.ab, a.H, a.W};
+    {
+        StatsSrc<3, 0, SHIFT> ss{g};
+        StatsDstP sd{sp, a.W, (float)a.eps};
+        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
+        if (rc != ASW_OK) return rc;
+    }
+    const ABTiles at = ab_tiles(a.H, a.W, a.r);
+    ABDstP dst{sp, nstat > 1 ? 1 : 0, reinterpret_cast<float2*>(a.ab), at, a.W};
     WalkOpts oab; oab.band = t.band_ab;
     WalkOpts oq; oq.band = t.band_q; oq.wg_strips = t.q_wg_strips;
     const int ring_ab = a.nan_safe ? 0 : t.ring_ab, ring_q = a.nan_safe ? 0 : t.ring_q;
-    if (ring_ab == 1) {  // ring = {cost, guide word}: 2 wavefronts per SIMD
+    if (ring_ab) {  // ring = {cost, guide word} of the last 15 rows of both columns: 2 wavefronts per SIMD
+        // (the ring holding the cost only and the leaving row's guide word fetched again -- 3 wavefronts per SIMD -- measured
+        // 0.3-0.4 ms slower: two more loads per step in a pass whose address unit is as busy as its VALU)
         ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
         rc = launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
-    } else if (ring_ab == 2) {  // ring = {cost}, the leaving row's guide word fetched again: 3 wavefronts per SIMD
-        ABSrc<3, SHIFT, false> src{g, a.P, a.pscales, a.H, a.W};
-        rc = launch_walk_t<4, 2, 1, 3, false, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
     } else {
         ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
-        rc = a.nan_safe ? launch_walk<4, 1, true>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab) : launch_walk<4>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
+        rc = a.nan_safe ? launch_walk_t<4, 2, 1, 3, true>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab)
+                        : launch_walk_t<4, 2, 1, 3, false>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
     }
     if (rc != ASW_OK) return rc;
-    QSrc<3> qs{a.ab, a.H, a.W};
-    QDst<3, SHIFT> qd{g, a.q, a.H, a.W};
-    if (ring_q == 1) return launch_walk_t<4, 1, 1, 4, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);  // one column per lane
-    if (ring_q == 2) return launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);  // two: 2 wavefronts per SIMD
-    return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
+    QSrcP qs{reinterpret_cast<const float2*>(a.ab), at};
+    auto run_q = [&](const auto& qd) {
+        // ring = {a_0, a_1, a_2, b} of the last 15 rows of both columns (128 registers): 2 wavefronts per SIMD.  One column per lane
+        // (4 wavefronts) measured 2.75 ms against 1.7: twice the wavefront-rows through the one LDS of the CU
+        if (ring_q) return launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
+        return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
+    };
+    if constexpr (SHIFT) {
+        QDst<3, true> qd{g, a.q, a.H, a.W};
+        return run_q(qd);
+    } else {
+        QDstP qd{g, a.q, a.H, a.W};
+        return run_q(qd);
+    }
 }
 
 }  // namespace
@@ -856,20 +1159,10 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         // GuidedF_2 / 3-channel getGuidedFilter: the guide does not depend on the slice.
         // 1. guide statistics, once   2. a, b   3. q
         GuideAccT<false> g{a.guideA, a.guideB, a.gscales, 0, a.W, 0, 0, a.minD};
-        StatsSrc<3, 0, false> ss{g};
-        StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
-        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, 1);
-        if (rc != ASW_OK) return rc;
-        return launch_ab_q3<false>(s, a, g, sp);
+        return launch_guided3<false>(s, a, g, 1);
     }
     GuideAccT<true> g{a.guideA, a.guideB, a.gscales, a.guide_per_slice ? 1 : 0, a.W, a.shiftA, a.shiftB, a.minD};
-    if (a.C == 3) {
-        StatsSrc<3, 0, true> ss{g};
-        StatsDst<0> sd{sp.half[0], sp, a.H, a.W, epsf};
-        rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
-        if (rc != ASW_OK) return rc;
-        return launch_ab_q3<true>(s, a, g, sp);
-    }
+    if (a.C == 3) return launch_guided3<true>(s, a, g, nstat);
     // 6-channel guide
     const bool share = a.guide_per_slice && a.rep_scratch && ((a.shiftA != 0) != (a.shiftB != 0));
     StatsSrc<6, 0, true> s0{g};
@@ -913,13 +1206,15 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
     // (boxes wider than 32 do not leave outputs in a 64-column strip: those take the two-column form at 148 VGPRs)
     if (a.r > 32)
-        rc = a.nan_safe ? launch_walk_t<7, 2, 1, 3, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 3>(s, src, dst, a.H, a.W, a.r, a.n);
+        rc = a.nan_safe ? launch_walk_t<7, 2, 1, 3, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 3, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     else
-        rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n);
+        rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1, 4, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
     QSrc<6> qs{a.ab, a.H, a.W};
     QDst<6, true> qd{g, a.q, a.H, a.W};
-    return a.nan_safe ? launch_walk<7, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk<7>(s, qs, qd, a.H, a.W, a.r, a.n);  // two columns per lane: 4.5 ms, one: 5.3 ms
+    // two columns per lane: 4.5 ms, one: 5.3 ms.  No load FIFO here (PF = 0): 16 floats per row and lane in flight twice over would
+    // cost the fourth wavefront per SIMD (5.1 ms at two)
+    return a.nan_safe ? launch_walk_t<7, 2, 1, 4, true, 0, 0>(s, qs, qd, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 4, false, 0, 0>(s, qs, qd, a.H, a.W, a.r, a.n);
 }
 
 // interleaved C-channel 8U image -> BGRX word planes (channels 3w..3w+2 in plane w)
@@ -942,5 +1237,13 @@ int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, in
 }
 
 // one [slot][H][W][8] array for a 3-channel guide; three for a 6-channel guide (word A, word B, unshifted word: StatsSplit)
-size_t guided_stats_floats(int C, int nstat, int H, int W) { return (size_t)nstat * H * W * 8 * (C == 3 ? 1 : 3); }
-size_t guided_ab_floats(int C, int n, int H, int W) { return (size_t)n * H * W * (C == 3 ? 4 : 8); }
+size_t guided_stats_floats(int C, int nstat, int H, int W)
+{
+    if (C == 3) return (size_t)nstat * H * W * 9 + 8;  // planar: three f64 + three f32 planes per slot, and room for the pair access at the last pixel
+    return (size_t)nstat * H * W * 8 * 3;
+}
+size_t guided_ab_floats(int C, int n, int H, int W, int r)
+{
+    if (C == 3) return (size_t)n * ab_tiles(H, W, r).slice_stride * 2 + 8;  // strip-major float2 tiles (ABTiles)
+    return (size_t)n * H * W * 8;
+}

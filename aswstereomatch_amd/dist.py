@@ -46,6 +46,8 @@ class Group:
         self.dist = None
         self.device = device
         self.backend = "none"
+        self.requested_backend = backend or "gloo"
+        self.rccl_error = None  # first line of the error that made an "nccl" group fall back to gloo
         if self.world > 1:
             import torch.distributed as dist
 
@@ -63,7 +65,8 @@ class Group:
                         raise
                     # The group carries a barrier and two scalar all-reduces, never image data: gloo over the loopback does
                     # that as well.  A second rendezvous needs its own port (rank 0's first store may still hold the old one).
-                    print("dist: RCCL process group failed (%s); falling back to gloo for the barrier / timing reductions" % str(e).splitlines()[0],
+                    self.rccl_error = (str(e).splitlines() or [type(e).__name__])[0][:300]
+                    print("dist: RCCL process group failed (%s); falling back to gloo for the barrier / timing reductions" % self.rccl_error,
                           file=sys.stderr, flush=True)
                     try:
                         dist.destroy_process_group()

@@ -45,9 +45,7 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(W, H, n_cand):
-    """inputs read once + aggregated f32 cost volume written once + f32 disparity."""
-    return 2 * W * H * 3 + W * H * n_cand * 4 + W * H * 4
+from aswstereomatch_amd.roofline import algorithmic_bytes  # noqa: E402  (shared with tools/pmc_traffic.py)
 
 
 def cpu_baseline(args, L, R, gpu_disp, alg):
@@ -306,6 +304,7 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     elapsed = group.max_over_ranks(elapsed)
     pids = group.gather_ints(os.getpid())  # one entry per rank: the line shows how many processes really ran
+    devices = group.gather_ints(device_index)  # the device index every rank bound (-1: dry run)
 
     if rank == 0:
         frames_total = args.frames * args.steps * world
@@ -319,8 +318,16 @@ def main(argv=None):
             "config": {"workload": "%dx%d D=%d win=%d %s, %d frames/GPU/step resident in HBM, cost volume kept"
                                    % (W, H, D, args.win, args.workload, args.frames),
                        "frames_per_gpu_per_step": args.frames, "candidates": ncand, "parallelism": "frames sharded, no collective",
-                       "ranks": world, "rank_pids": pids, "backend": group.backend if world > 1 else "none"},
+                       "ranks": world, "rank_pids": pids, "backend": group.backend if world > 1 else "none",
+                       # N > 1 on hardware: backend must read "nccl", rccl_ok true and devices 0..N-1, one process each -- a line
+                       # whose rccl_ok is false was synchronised over gloo (aswstereomatch_amd/dist.py) and says why
+                       "devices": devices,
+                       "rccl_ok": (group.backend == "nccl") if (world > 1 and group.requested_backend == "nccl") else None,
+                       "rccl_error": group.rccl_error},
         }
+        if world > 1 and not args.dry_run and (out["config"]["rccl_ok"] is False or len(set(pids)) != world or sorted(devices) != list(range(world))):
+            sys.stderr.write("bench.py: WARNING: this %d-GPU line is not one RCCL rank per device (backend %s, rccl_ok %s, %d processes, devices %s)\n"
+                             % (world, group.backend, out["config"]["rccl_ok"], len(set(pids)), devices))
         if args.dry_run:
             out["dry_run"] = True
             out["data"] = "synthetic (dry run: CPU checksum stand-in, not a measurement)"
@@ -332,16 +339,21 @@ def main(argv=None):
             traffic = None
             traffic_source = None
             pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-            if os.path.exists(pmc) and (W, H, D, args.win) == (1920, 1080, 128, 15):
+            if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                    traffic_source = ("recorded: profiles/pmc_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "workload, FETCH_SIZE doubled per the gfx950 note); not re-measured in this run" % args.workload)
+                    rec = json.load(open(pmc))
+                    # per FRAME, like algorithmic_bytes_per_launch below (the "launch" of this line is the frame's set of
+                    # aggregation launches); only when the record was taken at this very shape
+                    if rec.get("shape") == [W, H, D, args.win]:
+                        traffic = rec.get("hbm_bytes_per_frame")
+                        traffic_source = ("recorded: profiles/pmc_%s.json, bytes per frame over all aggregation launches (rocprofv3 --pmc "
+                                          "FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled per the gfx950 note); "
+                                          "not re-measured in this run" % args.workload)
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                               "kernel": "aggregate", "algorithmic_bytes_per_launch": balg,
+                               "kernel": "aggregate (all aggregation launches of one frame)", "algorithmic_bytes_per_launch": balg,
                                "avg_launch_ms": round(agg_per_frame_ms / max(1, launches / n_frames_rank), 4),
                                "launches_per_frame": launches / n_frames_rank}
             out["kernel_ms_per_frame"] = {"aggregate": round(agg_per_frame_ms, 4), "all": round(tot_ms / n_frames_rank, 4)}

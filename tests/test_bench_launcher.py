@@ -39,6 +39,17 @@ def test_gpus_2_spawns_two_ranks_itself():
     assert abs(out["value"] - 96 * 64 * 3 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3) / 1e6) <= 0.02 * out["value"] + 1e-3
 
 
+def test_gpus_8_dry_run_is_eight_processes_and_says_how_it_was_synchronised():
+    # the shape of the first real 8-GPU line, rehearsed on CPU: eight ranks, eight distinct processes; a dry run never claims RCCL
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"] + SMALL, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["ranks"] == 8 and len(cfg["rank_pids"]) == 8 and len(set(cfg["rank_pids"])) == 8
+    assert cfg["backend"] == "gloo" and cfg["rccl_ok"] is None and cfg["rccl_error"] is None  # gloo was asked for: nothing fell back
+    assert cfg["devices"] == [-1] * 8  # no device in a dry run; on hardware: [0, 1, ..., 7]
+
+
 def test_under_an_external_launcher_each_process_is_one_rank():
     # what `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` gives every process
     procs = []

@@ -64,7 +64,7 @@ def test_xq_right_matches_oracle_and_one_kernel_path(ctx, ctx_old, oracle, H, W,
     assert np.array_equal(v, v0, equal_nan=True) and np.array_equal(d, d0)
 
 
-def test_xq_right_mid_size_and_lr_check(ctx):
+def test_xq_right_mid_size_and_lr_check(ctx, ctx_old):
     L, R, _ = make_pair(135, 480, 128, seed=15)
     d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
     d0, v0 = ctx_old.computeAdaptiveWeight(L, R, 30, 20, RIGHT, 15, 0, 128, return_cost_volume=True)
@@ -102,7 +102,7 @@ def test_other_windows_stay_on_the_one_kernel_path(ctx, ctx_old, oracle):
         assert rc == 0 and np.array_equal(v, vw, equal_nan=True) and np.array_equal(d, dw), (dt, win)
 
 
-def test_xq_mid_size_equals_one_kernel_path(ctx):
+def test_xq_mid_size_equals_one_kernel_path(ctx, ctx_old):
     # 270 x 480, D = 128: too long for the oracle in a unit test, so the two GPU paths check each other (the one-kernel path
     # is itself checked against the oracle at this size by the fuzz sweeps and at 1080p on row bands)
     L, R, _ = make_pair(270, 480, 128, seed=14)
