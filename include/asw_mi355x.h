@@ -35,7 +35,7 @@ typedef enum asw_status {
     ASW_OK = 0,
     ASW_ERR_SIZE_MISMATCH = 1,      /* M.cpp:217-220, 313-316, 430-433: silent return          */
     ASW_ERR_EVEN_WINDOW = 2,        /* M.cpp:654-657, 1440-1443, 2458-2462, 3238-3241: Mat()  */
-    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values outside the hot path (0,1,5)               */
+    ASW_ERR_UNSUPPORTED_METHOD = 3, /* enum values 0 and 1 (BM, SGBM: OpenCV's own matchers) */
     ASW_ERR_UNSUPPORTED_LAYOUT = 4, /* where the reference throws cv::Exception (SURVEY B-7)  */
     ASW_ERR_HIP = 5,                /* a HIP runtime call or kernel launch failed             */
     ASW_ERR_ALLOC = 6,

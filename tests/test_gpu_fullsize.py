@@ -75,6 +75,22 @@ def test_c5_frame_1080p_classic_right_rows_vs_oracle(ctx, oracle):
     assert np.array_equal(d, d0) and np.array_equal(v, v0, equal_nan=True)
 
 
+@pytest.mark.parametrize("dt", [LEFT, RIGHT])
+def test_c5_frame_1080p_classic_whole_frame_vs_oracle(ctx, oracle, dt):
+    """The headline configuration (BASELINE.json metric: 1920x1080, D=128, win 15, classic bilateral ASW) against the CPU
+    restatement over ALL 1080 rows, both disparity directions: the 129 volume planes and the WTA map bit for bit
+    (M.cpp:1074-1153; RIGHT: M.cpp:1113-1142).  ~15 s of oracle time per direction on 16 host cores.  The restatement is
+    pinned by nothing the reference holds (parity unpinned): this shows the kernel equals the restatement
+    on every pixel of the frame the bench times, not that either equals the reference."""
+    L, R, _ = make_pair(1080, 1920, 128, seed=1234)
+    d, v = ctx.computeAdaptiveWeight(L, R, 30, 20, dt, 15, 0, 128, return_cost_volume=True)
+    rc, dw, vw = oracle.asw_classic(L, R, 30, 20, int(dt), 15, 0, 128, want_vol=True)
+    assert rc == 0 and v.shape == vw.shape == (129, 1080, 1920)
+    for k in range(v.shape[0]):  # plane by plane: a failure names its plane
+        assert np.array_equal(v[k], vw[k], equal_nan=True), (k, int((v[k] != vw[k]).sum()))
+    assert np.array_equal(d, dw), int((d != dw).sum())
+
+
 def test_c3_1080p_guided2_properties(ctx):
     # configs[2]: 1920x1080, D=128, guided-filter ASW
     L, R, gt = make_pair(1080, 1920, 128, seed=77)
