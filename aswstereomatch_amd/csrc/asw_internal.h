@@ -123,8 +123,8 @@ struct BilateralLaunch {
 // xq form of the classic kernel (k_bilateral_xq.hip): candidates [0, bilateral_xq_candidates()) of a DISPARITY_LEFT, win = 15
 // problem with at least that many candidates; writes the running minimum to bestE / bestD for the tail launch, or -- when
 // there is no tail (disp != nullptr) -- the disparity itself
-int bilateral_xq_candidates();
-int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
+int bilateral_xq_candidates(int nwave);  // nwave = 8 / 4 wavefronts per workgroup: 128 / 64 candidates
+int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
                         const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right = false);
 int launch_bilateral(hipStream_t s, const BilateralLaunch& a);
 // winners of per-slice partial WTAs (candidate range split over grid.z for small frames) -> disparity, strict '<' in ascending d

@@ -143,12 +143,14 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
     a.vol = keep_volume ? f->vol.as<float>() : nullptr;
     a.disp = f->disp.as<float>();
     a.partE = nullptr; a.partD = nullptr; a.max_slices = 0;
-    // Long candidate ranges of the reference's own configuration (15x15, either direction) take the xq form of the kernel for the
-    // first 128 candidates and this kernel for the tail.  The tile of the outermost workgroup must still hold the eight image
+    // Candidate ranges of the reference's own configuration (15x15, either direction) from 64 candidates up take the xq form of the
+    // kernel for the first 128 (8 wavefronts per workgroup) or 64 (4 wavefronts: the reference's own call site passes
+    // numDisparity 64 -> 65 candidates, aswStereoMatch.cpp:94) and this kernel for the tail.  The tile of the outermost workgroup must still hold the eight image
     // columns next to the border its positions clamp to: LEFT minD <= 48 (columns 0..7 in the first tile), RIGHT
     // x0_last + minD <= W - 1 (columns W-8..W-1 in the last).  ASW_BILATERAL_XQ=0 forces the one-kernel path (A/B, tests).
     const bool xq_fits = flip ? (W - 1) / 64 * 64 + mp.minD <= W - 1 : mp.minD <= 48;
-    const bool use_xq = !direct8 && mp.win == 15 && nD >= bilateral_xq_candidates() && mp.minD >= 0 && xq_fits && W >= 64 &&
+    const int xq_waves = nD >= bilateral_xq_candidates(8) ? 8 : 4;
+    const bool use_xq = !direct8 && mp.win == 15 && nD >= bilateral_xq_candidates(xq_waves) && mp.minD >= 0 && xq_fits && W >= 64 &&
                         ctx->tune.bilateral_xq != 0;
     if (use_xq) {
         DevBuf& pe = ctx->buf("bil_partE");
@@ -157,19 +159,19 @@ static int run_bilateral(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool kee
         ASW_TRY(pe.ensure(2 * plane * sizeof(double)));
         ASW_TRY(pd.ensure(2 * plane * sizeof(float)));
         a.partE = pe.as<double>(); a.partD = pd.as<float>(); a.max_slices = 2;
-        a.c_begin = bilateral_xq_candidates();
-        const bool tail = nD > a.c_begin;  // numDisparity = 127 ends exactly at the xq kernel's 128 candidates
+        a.c_begin = bilateral_xq_candidates(xq_waves);
+        const bool tail = nD > a.c_begin;  // numDisparity = 127 / 63 ends exactly at the xq kernel's 128 / 64 candidates
         ASW_HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
         // fork: border tiles and the tail are independent of the interior launch (they write other pixels / another slice of the
         // per-slice winners); on side streams they overlap it instead of adding two latency-bound 0.5 ms launches to the frame
         ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[0], ctx->stream));
         ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->aux_ev[0], 0));
-        ASW_TRY(launch_bilateral_xq(ctx->stream, ctx->aux[0], a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol,
+        ASW_TRY(launch_bilateral_xq(ctx->stream, ctx->aux[0], xq_waves, a.gL, a.gR, H, W, mp.minD, ctx->bil.cells.as<int4>(), a.lut, a.vol,
                                     a.partE, a.partD, tail ? nullptr : a.disp, flip != 0));
         ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[1], ctx->aux[0]));
         if (tail) {
             ASW_HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->aux_ev[0], 0));
-            a.out_slice = 1;  // candidates [128, nD) -> slice 1; the xq launches fill slice 0
+            a.out_slice = 1;  // candidates [128 | 64, nD) -> slice 1; the xq launches fill slice 0
             ASW_TRY(launch_bilateral(ctx->aux[1], a));
             ASW_HIP_TRY(hipEventRecord(ctx->aux_ev[2], ctx->aux[1]));
             ASW_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_ev[2], 0));

@@ -46,31 +46,55 @@ namespace {
 constexpr int HH = 7;                     // half window
 constexpr int KS = 2 * HH + 1;            // 15
 constexpr int PXW = 64;                   // pixels per workgroup
-constexpr int NWAVE = 8;
-constexpr int NJ = 4 * NWAVE;             // position blocks per workgroup (+ the wrapped units of block NJ)
-constexpr int NPOS = PXW + 4 * NJ;        // 192 right-image positions a workgroup touches: [posmin, posmin + 191]
 constexpr int LWC = PXW + 2 * HH;         // left tile columns  [x0 - 7, x0 + 70]
-constexpr int RWC = NPOS + 2 * HH;        // right tile columns [posmin - 7, posmin + 198]
 constexpr int NSTEP = KS + 3;             // 18 steps: unit row b runs b tap columns behind
 constexpr int RING = 5;                   // tap columns of left weights kept (4 in use + the one being staged)
-constexpr int NFIN = 4 * NJ;              // candidates [0, 128) are finished by this kernel
 constexpr int NCELLCOL = NSTEP + 3;       // cell-table columns kx = -3 .. 17
+constexpr int LW8 = 80;                   // u8 row stride of the left tile (multiple of 4)
 
-// LDS layout (bytes)
-constexpr int OFF_LD = 0;                               // double [KS][LWC]   left gray
-constexpr int OFF_RD = OFF_LD + KS * LWC * 8;           // double [KS][RWC]   right gray
-constexpr int OFF_WL = OFF_RD + KS * RWC * 8;           // float  [RING][KS][PXW]
-constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;    // float  [2][KS][NPOS]
-constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;      // u8     [KS][LW8]
-constexpr int LW8 = 80, RW8 = 208;                      // u8 row strides (multiples of 4)
-constexpr int OFF_R8 = OFF_L8 + KS * LW8;
-constexpr int OFF_CELL = OFF_R8 + KS * RW8;             // u16 [NCELLCOL * KS]: packed cell table
-constexpr int LDS_TOTAL = (OFF_CELL + NCELLCOL * KS * 2 + 15) / 16 * 16;  // 81 280 B: two workgroups per CU
-constexpr int OFF_E64 = 0;                              // epilogue: double [NFIN][PXW] = 65 536 B over the dead tiles
-constexpr int OFF_PART = NFIN * PXW * 8;                // epilogue: per-part WTA partials, double E[NWAVE][PXW], float d[NWAVE][PXW]
-static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
-static_assert(OFF_PART + NWAVE * PXW * 12 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
-static_assert(OFF_RD % 16 == 0 && OFF_WL % 16 == 0 && OFF_WR % 16 == 0 && (KS * NPOS * 4) % 16 == 0 && (NPOS * 4) % 16 == 0, "b128 alignment");
+// Everything that depends on the number of wavefronts NW of a workgroup (8: 128 candidates per pass -- the reference's
+// configuration at 1080p; 4: 64 candidates -- its own call site, aswStereoMatch.cpp:94, numDisparity 64 -> 65 candidates):
+//   NJ    position blocks per workgroup (+ the wrapped units of block NJ)
+//   NPOS  right-image positions a workgroup touches: [posmin, posmin + NPOS - 1]
+//   RWC   right tile columns [posmin - 7, posmin + NPOS + 6]
+//   NFIN  candidates [0, NFIN) are finished by the kernel
+// LDS layout (bytes): double [KS][LWC] left gray | double [KS][RWC] right gray | float [RING][KS][PXW] left weights |
+// float [2][KS][NPOS] right weights | u8 [KS][LW8] | u8 [KS][RW8] | u16 [NCELLCOL * KS] packed cell table.
+// Epilogue (over the dead tiles): double [NFIN][PXW] E | per-part WTA partials double E[NW][PXW], float d[NW][PXW].
+// NW = 8: 81 280 B, two workgroups = 16 wavefronts per CU; NW = 4: 62 KB, two workgroups = 8 wavefronts per CU.
+template <int NW>
+struct XqCfg {
+    static constexpr int NWAVE = NW;
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int NJ = 4 * NW;
+    static constexpr int NPOS = PXW + 4 * NJ;
+    static constexpr int RWC = NPOS + 2 * HH;
+    static constexpr int NFIN = 4 * NJ;
+    static constexpr int RW8 = (RWC + 3) / 4 * 4;
+    static constexpr int NROWS = (KS + NW - 1) / NW;  // window rows a wavefront stages
+    static constexpr int OFF_LD = 0;
+    static constexpr int OFF_RD = OFF_LD + KS * LWC * 8;
+    static constexpr int OFF_WL = OFF_RD + KS * RWC * 8;
+    static constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;
+    static constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;
+    static constexpr int OFF_R8 = OFF_L8 + KS * LW8;
+    static constexpr int OFF_CELL = OFF_R8 + KS * RW8;
+    static constexpr int LDS_TOTAL = (OFF_CELL + NCELLCOL * KS * 2 + 15) / 16 * 16;
+    static constexpr int OFF_E64 = 0;
+    static constexpr int OFF_PART = NFIN * PXW * 8;
+    static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
+    static_assert(OFF_PART + NW * PXW * 12 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
+    static_assert(OFF_RD % 16 == 0 && OFF_WL % 16 == 0 && OFF_WR % 16 == 0 && (KS * NPOS * 4) % 16 == 0 && (NPOS * 4) % 16 == 0, "b128 alignment");
+    static_assert(NPOS % 64 == 0, "positions are staged in whole wavefront passes");
+};
+#define XQ_CONSTS(NW)                                                                                                           \
+    typedef XqCfg<NW> Cfg;                                                                                                       \
+    constexpr int NWAVE = Cfg::NWAVE, NTHR = Cfg::NTHR, NJ = Cfg::NJ, NPOS = Cfg::NPOS, RWC = Cfg::RWC, NFIN = Cfg::NFIN, RW8 = Cfg::RW8,      \
+                  NROWS = Cfg::NROWS, OFF_LD = Cfg::OFF_LD, OFF_RD = Cfg::OFF_RD, OFF_WL = Cfg::OFF_WL, OFF_WR = Cfg::OFF_WR,    \
+                  OFF_L8 = Cfg::OFF_L8, OFF_R8 = Cfg::OFF_R8, OFF_CELL = Cfg::OFF_CELL, LDS_TOTAL = Cfg::LDS_TOTAL,              \
+                  OFF_E64 = Cfg::OFF_E64, OFF_PART = Cfg::OFF_PART;                                                              \
+    (void)NWAVE; (void)NTHR; (void)NJ; (void)NPOS; (void)RWC; (void)NFIN; (void)RW8; (void)NROWS; (void)OFF_LD; (void)OFF_RD; (void)OFF_WL; \
+    (void)OFF_WR; (void)OFF_L8; (void)OFF_R8; (void)OFF_CELL; (void)LDS_TOTAL; (void)OFF_E64; (void)OFF_PART;
 
 struct XqParams {
     int H, W, minD;
@@ -83,8 +107,10 @@ __device__ __forceinline__ float lut_at(const float* __restrict__ lut, unsigned 
 }
 
 // packed cell table in LDS: (dxw + 8) | (dyw + 8) << 4 | class << 8
+template <int NW>
 __device__ __forceinline__ void cell_at(const unsigned char* smem, int idx, int& dxw, int& dyw, int& cls256)
 {
+    XQ_CONSTS(NW)
     const uint32_t u = reinterpret_cast<const uint16_t*>(smem + OFF_CELL)[idx];
     dxw = (int)(u & 15u) - 8;
     dyw = (int)((u >> 4) & 15u) - 8;
@@ -99,20 +125,22 @@ __device__ __forceinline__ void cell_at(const unsigned char* smem, int idx, int&
 // pass + gathers, at the top of the step) and stage_commit (LDS writes, in the middle of the step's row loop).  Done in one
 // piece in front of the step, the staging cost 10 % of the kernel for 5 % of its instructions: eight wavefronts waiting for
 // the same two memory round trips (ablation: profiles/r02/ablation_*.csv).
-struct Staged { float v[2][1 + NPOS / 64]; };
+template <int NW> struct Staged { float v[XqCfg<NW>::NROWS][1 + XqCfg<NW>::NPOS / 64]; };
 
+template <int NW>
 __device__ __forceinline__ void stage_issue(int Kn, const float* __restrict__ lut, const unsigned char* smem, int wave, int lane,
-                                            int ctrL, int pclamp_lo, int pclamp_hi, Staged& st)
+                                            int ctrL, int pclamp_lo, int pclamp_hi, Staged<NW>& st)
 {
+    XQ_CONSTS(NW)
     const uint8_t* sL8 = smem + OFF_L8;
     const uint8_t* sR8 = smem + OFF_R8;
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int ky = wave + 8 * rr;
+    for (int rr = 0; rr < NROWS; rr++) {
+        const int ky = wave + NWAVE * rr;
         if (ky >= KS) break;  // wave-uniform
         int dxw, dyw, cls;
         if (Kn < KS) {        // left column Kn exists
-            cell_at(smem, (Kn + 3) * KS + ky, dxw, dyw, cls);
+            cell_at<NW>(smem, (Kn + 3) * KS + ky, dxw, dyw, cls);
             const int nb = sL8[(HH + dyw) * LW8 + (lane + HH + dxw)];
             st.v[rr][0] = lut_at(lut, __builtin_amdgcn_sad_u16(nb, ctrL, cls));
         }
@@ -120,7 +148,7 @@ __device__ __forceinline__ void stage_issue(int Kn, const float* __restrict__ lu
         for (int r3 = 0; r3 < NPOS / 64; r3++) {
             const int p = lane + 64 * r3;
             const int b = p & 3;  // posmin == Q (mod 4): the unit row a position belongs to is a property of the position
-            cell_at(smem, (Kn - b + 3) * KS + ky, dxw, dyw, cls);
+            cell_at<NW>(smem, (Kn - b + 3) * KS + ky, dxw, dyw, cls);
             // the weight is evaluated AT max(0, x - d) (M.cpp:1105); its neighbour is clamped from there (tile columns are
             // replicate-clamped, so adding the direction needs no further clamp)
             const int pc = min(max(p, pclamp_lo), pclamp_hi) + HH;  // tile column of the clamped position
@@ -131,13 +159,15 @@ __device__ __forceinline__ void stage_issue(int Kn, const float* __restrict__ lu
     }
 }
 
-__device__ __forceinline__ void stage_commit(int Kn, unsigned char* smem, int wave, int lane, const Staged& st)
+template <int NW>
+__device__ __forceinline__ void stage_commit(int Kn, unsigned char* smem, int wave, int lane, const Staged<NW>& st)
 {
+    XQ_CONSTS(NW)
     float* sWL = reinterpret_cast<float*>(smem + OFF_WL) + (Kn % RING) * (KS * PXW);
     float* sWR = reinterpret_cast<float*>(smem + OFF_WR) + (Kn & 1) * (KS * NPOS);
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int ky = wave + 8 * rr;
+    for (int rr = 0; rr < NROWS; rr++) {
+        const int ky = wave + NWAVE * rr;
         if (ky >= KS) break;
         if (Kn < KS) sWL[ky * PXW + lane] = st.v[rr][0];
 #pragma unroll
@@ -145,12 +175,13 @@ __device__ __forceinline__ void stage_commit(int Kn, unsigned char* smem, int wa
     }
 }
 
+template <int NW>
 __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ lut, unsigned char* smem, int wave, int lane,
                                               int ctrL, int pclamp_lo, int pclamp_hi)
 {
-    Staged st;
-    stage_issue(Kn, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);
-    stage_commit(Kn, smem, wave, lane, st);
+    Staged<NW> st;
+    stage_issue<NW>(Kn, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);
+    stage_commit<NW>(Kn, smem, wave, lane, st);
 }
 
 // One step: window rows ky = 0..14 of tap column K - b for every active unit row b (BLO <= b <= BHI).
@@ -160,11 +191,12 @@ __device__ __forceinline__ void stage_weights(int Kn, const float* __restrict__ 
 // Units with a < b (RIGHT: b < a) take their position from qrel2 / dbase2 (== qrel / dbase except in the threads of block
 // j = 0, where they are the wrapped units of block 32).
 // WRAPW: this wavefront holds the threads of block j = 0 (wave 0).  Elsewhere qrel2 == qrel and the second loads are skipped.
-template <int K, bool EDGE, bool WRAPW, bool COMMIT, bool RIGHT>
+template <int NW, int K, bool EDGE, bool WRAPW, bool COMMIT, bool RIGHT>
 __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                          int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4], int wave, int lane,
-                                         const Staged& st)
+                                         const Staged<NW>& st)
 {
+    XQ_CONSTS(NW)
     constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;  // kx = K - b <= 14
     constexpr int BHI = K < 3 ? K : 3;                  // kx = K - b >= 0
     constexpr int DLO = 0 - BHI, DHI = 3 - BLO;         // diagonals a - b in use
@@ -194,7 +226,7 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
 #pragma unroll 1
     for (int ky = 0; ky < KS; ky++) {
         if constexpr (COMMIT) {
-            if (ky == KS / 2) stage_commit(K + 1, smem, wave, lane, st);  // the gathers issued before this loop have landed
+            if (ky == KS / 2) stage_commit<NW>(K + 1, smem, wave, lane, st);  // the gathers issued before this loop have landed
         }
         double c[7];
         if constexpr (!EDGE) {
@@ -239,18 +271,18 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
 }
 
 // ABL (timing experiments only, results are wrong): bit 0 = no weight staging after step 0, bit 1 = no barriers between steps
-template <bool EDGE, bool WRAPW, int ABL, bool RIGHT>
+template <int NW, bool EDGE, bool WRAPW, int ABL, bool RIGHT>
 __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* __restrict__ lut, int wave, int lane, int ctrL,
                                               int pclamp_lo, int pclamp_hi, int g, int qrel, int qrel2, int xabs, int dbase, int dbase2,
                                               int W, int x0, int posmin, double (&num)[4][4], double (&den)[4][4])
 {
-    Staged st;
+    Staged<NW> st;
 #define ASW_XQ_STEP(KK)                                                                                        \
     if (!(ABL & 1) && (KK) + 1 < NSTEP) {                                                                        \
-        if constexpr (EDGE) stage_weights((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);  /* border tiles: registers are scarcer there */ \
-        else stage_issue((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);                      \
+        if constexpr (EDGE) stage_weights<NW>((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);  /* border tiles: registers are scarcer there */ \
+        else stage_issue<NW>((KK) + 1, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi, st);                      \
     }                                                                                                           \
-    run_step<(KK), EDGE, WRAPW, (!EDGE && !(ABL & 1) && (KK) + 1 < NSTEP), RIGHT>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, \
+    run_step<NW, (KK), EDGE, WRAPW, (!EDGE && !(ABL & 1) && (KK) + 1 < NSTEP), RIGHT>(smem, g, qrel, qrel2, xabs, dbase, dbase2, W, x0, posmin, \
                                                                            num, den, wave, lane, st);          \
     if (!(ABL & 2) || (KK) == NSTEP - 1) __syncthreads();
     ASW_XQ_STEP(0) ASW_XQ_STEP(1) ASW_XQ_STEP(2) ASW_XQ_STEP(3) ASW_XQ_STEP(4) ASW_XQ_STEP(5)
@@ -262,14 +294,15 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* 
 // grid (tiles of this launch, H), 512 threads.  gL / gR: gray planes [H][W].  vol (optional): [>= NFIN][H][W].
 // bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
 // launch to resume from; disp (when there is no tail): the disparity itself.
-template <bool EDGE, int ABL, bool RIGHT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_asw_bilateral_xq(
+template <int NW, bool EDGE, int ABL, bool RIGHT>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
     float* __restrict__ disp)
 {
     // static: the LDS base is then a compile-time 0 and folds into the instructions' offset fields (with the dynamic-LDS
     // symbol every address in the step loop carried its own "v_add_u32 v, <base>, v": 6 of 78 VALU instructions)
+    XQ_CONSTS(NW)
     __shared__ __align__(16) unsigned char smem[LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
@@ -282,14 +315,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         uint8_t* sR8 = smem + OFF_R8;
         double* sLd = reinterpret_cast<double*>(smem + OFF_LD);
         double* sRd = reinterpret_cast<double*>(smem + OFF_RD);
-        for (int i = tid; i < KS * LWC; i += 512) {
+        for (int i = tid; i < KS * LWC; i += NTHR) {
             const int r = i / LWC, c = i - r * LWC;
             const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(x0 - HH + c, 0), W - 1);
             const int v = gL[(size_t)yy * W + xx];
             sL8[r * LW8 + c] = (uint8_t)v;
             sLd[r * LWC + c] = (double)v;
         }
-        for (int i = tid; i < KS * RWC; i += 512) {
+        for (int i = tid; i < KS * RWC; i += NTHR) {
             const int r = i / RWC, c = i - r * RWC;
             const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(posmin - HH + c, 0), W - 1);
             const int v = gR[(size_t)yy * W + xx];
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             sRd[r * RWC + c] = (double)v;
         }
         uint16_t* sCell = reinterpret_cast<uint16_t*>(smem + OFF_CELL);
-        for (int i = tid; i < NCELLCOL * KS; i += 512) {
+        for (int i = tid; i < NCELLCOL * KS; i += NTHR) {
             const int4 ci = cells[i];
             sCell[i] = (uint16_t)((uint32_t)(ci.x + 8) | ((uint32_t)(ci.y + 8) << 4) | ((uint32_t)(ci.z >> 8) << 8));
         }
@@ -327,15 +360,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int b = 0; b < 4; b++) { num[a][b] = 0.0; den[a][b] = 0.0; }
 
-    stage_weights(0, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
+    stage_weights<NW>(0, lut, smem, wave, lane, ctrL, pclamp_lo, pclamp_hi);
     __syncthreads();
     // wave 0 holds the threads of block j = 0 (the wrapped units): its steps load the second right weights / gray; ONE branch
     // around the whole step sequence (a branch per step made the register allocator spill 488 VGPRs)
     if (EDGE || wave == 0)
-        run_all_steps<EDGE, true, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+        run_all_steps<NW, EDGE, true, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                    x0, posmin, num, den);
     else
-        run_all_steps<EDGE, false, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
+        run_all_steps<NW, EDGE, false, ABL, RIGHT>(smem, lut, wave, lane, ctrL, pclamp_lo, pclamp_hi, g, qrel, qrel2, xabs, dbase, dbase2, W,
                                                     x0, posmin, num, den);
     // (the last step ended with a barrier: the tiles are dead)
 
@@ -386,26 +419,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 }  // namespace
 
-int bilateral_xq_candidates() { return NFIN; }
+int bilateral_xq_candidates(int nwave) { return 16 * nwave; }
 
-// cells: int4[21 * 15] {dxw, dyw, class * 256, -} per window cell, kx = -3..17; lut: float[ncls][256] with an all-zero class.
-// disp != nullptr: the launch covers the whole candidate range (nD == 128): write the disparity; else bestE / bestD.
-// s_border: stream of the border-tile launch (may equal s; a side stream lets the 1/30 of the tiles overlap the main launch)
-// right: DISPARITY_RIGHT -- gL is then the fixed (right) image's gray plane and gR the left image's.
-int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
-                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right)
+namespace {
+template <int NW>
+int launch_xq_t(hipStream_t s, hipStream_t s_border, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD, const int4* cells,
+                const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right)
 {
     const int ntiles = (W + PXW - 1) / PXW;
+    const dim3 blk(64 * NW);
     if (right) {
         // border tile = the first of a row (windows of x < 7 clamp at column 0); the clamped positions' weight neighbours
         // (columns W-8 .. W-1) must lie in the last tile's right-gray tile: x0_last + minD <= W - 1
         if ((ntiles - 1) * PXW + minD > W - 1) return ASW_ERR_BAD_ARGUMENT;
         XqParams pe{H, W, minD, 0};
-        hipLaunchKernelGGL((k_asw_bilateral_xq<true, 0, true>), dim3(1, H), dim3(512), 0, s_border, pe, gL, gR, cells, lut, vol,
+        hipLaunchKernelGGL((k_asw_bilateral_xq<NW, true, 0, true>), dim3(1, H), blk, 0, s_border, pe, gL, gR, cells, lut, vol,
                            bestE, bestD, disp);
         if (ntiles > 1) {
             XqParams pi{H, W, minD, 1};
-            hipLaunchKernelGGL((k_asw_bilateral_xq<false, 0, true>), dim3(ntiles - 1, H), dim3(512), 0, s, pi, gL, gR, cells, lut,
+            hipLaunchKernelGGL((k_asw_bilateral_xq<NW, false, 0, true>), dim3(ntiles - 1, H), blk, 0, s, pi, gL, gR, cells, lut,
                                vol, bestE, bestD, disp);
         }
         ASW_HIP_TRY(hipGetLastError());
@@ -416,20 +448,34 @@ int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, const uint8_t* gL, 
 #ifdef ASW_XQ_ABLATION  // measurement builds only (HIPCC_EXTRA=-DASW_XQ_ABLATION): the ablated kernels compute wrong results
     int abl = 0;
     if (const char* e = getenv("ASW_XQ_ABLATE")) abl = atoi(e) & 3;  // profiles/r02/ablation/*.csv
-    auto ki = abl == 0 ? k_asw_bilateral_xq<false, 0, false> : abl == 1 ? k_asw_bilateral_xq<false, 1, false>
-            : abl == 2 ? k_asw_bilateral_xq<false, 2, false> : k_asw_bilateral_xq<false, 3, false>;
+    auto ki = abl == 0 ? k_asw_bilateral_xq<NW, false, 0, false> : abl == 1 ? k_asw_bilateral_xq<NW, false, 1, false>
+            : abl == 2 ? k_asw_bilateral_xq<NW, false, 2, false> : k_asw_bilateral_xq<NW, false, 3, false>;
 #else
-    auto ki = k_asw_bilateral_xq<false, 0, false>;
+    auto ki = k_asw_bilateral_xq<NW, false, 0, false>;
 #endif
-    auto ke = k_asw_bilateral_xq<true, 0, false>;
+    auto ke = k_asw_bilateral_xq<NW, true, 0, false>;
     if (n_int > 0) {
         XqParams p{H, W, minD, 0};
-        hipLaunchKernelGGL(ki, dim3(n_int, H), dim3(512), 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
+        hipLaunchKernelGGL(ki, dim3(n_int, H), blk, 0, s, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
     }
     if (ntiles > n_int) {
         XqParams p{H, W, minD, n_int};
-        hipLaunchKernelGGL(ke, dim3(ntiles - n_int, H), dim3(512), 0, s_border, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
+        hipLaunchKernelGGL(ke, dim3(ntiles - n_int, H), blk, 0, s_border, p, gL, gR, cells, lut, vol, bestE, bestD, disp);
     }
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
+}
+}  // namespace
+
+// nwave: 8 = candidates [0, 128), 4 = candidates [0, 64).
+// cells: int4[21 * 15] {dxw, dyw, class * 256, -} per window cell, kx = -3..17; lut: float[ncls][256] with an all-zero class.
+// disp != nullptr: the launch covers the whole candidate range: write the disparity; else bestE / bestD.
+// s_border: stream of the border-tile launch (may equal s; a side stream lets the 1/30 of the tiles overlap the main launch)
+// right: DISPARITY_RIGHT -- gL is then the fixed (right) image's gray plane and gR the left image's.
+int launch_bilateral_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint8_t* gL, const uint8_t* gR, int H, int W, int minD,
+                        const int4* cells, const float* lut, float* vol, double* bestE, float* bestD, float* disp, bool right)
+{
+    if (nwave == 8) return launch_xq_t<8>(s, s_border, gL, gR, H, W, minD, cells, lut, vol, bestE, bestD, disp, right);
+    if (nwave == 4) return launch_xq_t<4>(s, s_border, gL, gR, H, W, minD, cells, lut, vol, bestE, bestD, disp, right);
+    return ASW_ERR_BAD_ARGUMENT;
 }

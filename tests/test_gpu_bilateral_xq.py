@@ -31,7 +31,9 @@ def ctx_old():
 # (H, W, minD, numD): one and several 64-pixel tiles, partial last tile, the tile whose windows reach the right border,
 # W < numD (every position clamps to column 0 somewhere), minD > 0, tails of 4 / 5 / 16+ candidates
 SHAPES = [(5, 64, 0, 128), (9, 200, 0, 128), (3, 257, 2, 128), (17, 130, 0, 127), (4, 333, 48, 131), (2, 71, 0, 160),
-          (21, 96, 7, 128), (1, 640, 0, 128)]
+          (21, 96, 7, 128), (1, 640, 0, 128),
+          # 64..127 candidates: the 4-wavefront form (64 candidates per pass; the reference's own call passes numDisparity 64)
+          (5, 64, 0, 64), (9, 200, 0, 63), (3, 257, 2, 100), (4, 333, 48, 70), (2, 71, 0, 90), (17, 130, 0, 126), (1, 640, 5, 64)]
 
 
 @pytest.mark.parametrize("H,W,minD,numD", SHAPES)
@@ -49,7 +51,8 @@ def test_xq_matches_oracle_and_one_kernel_path(ctx, ctx_old, oracle, H, W, minD,
 # DISPARITY_RIGHT (M.cpp:1113-1142): positions run to the right, the border tile is the first of a row; minD > 0 only while the
 # last tile still holds columns W-8..W-1 (x0_last + minD <= W - 1), else the one-kernel path serves the call
 RIGHT_SHAPES = [(5, 64, 0, 128), (9, 200, 0, 128), (3, 257, 0, 128), (17, 130, 1, 127), (4, 333, 12, 131), (2, 71, 6, 160),
-                (21, 96, 7, 128), (1, 640, 0, 128), (3, 200, 40, 128)]
+                (21, 96, 7, 128), (1, 640, 0, 128), (3, 200, 40, 128),
+                (5, 64, 0, 64), (9, 200, 0, 63), (3, 257, 0, 100), (4, 333, 12, 70), (2, 71, 6, 90), (1, 640, 3, 64)]
 
 
 @pytest.mark.parametrize("H,W,minD,numD", RIGHT_SHAPES)

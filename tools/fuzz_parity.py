@@ -78,7 +78,7 @@ def main():
             H, W = int(rng.integers(1, 10)), int(rng.integers(64, 420))
             win, dt = 15, int(rng.integers(0, 2))   # both directions have an xq form
             minD = int(rng.choice([0, 0, 1, 5, 48, 49, 70])) if method == "classic" else int(rng.choice([0, 0, 2, 33, 130]))
-            numD = int(rng.choice([63, 64, 127, 128, 129, 191, 192, 255, int(rng.integers(63, 300))]))
+            numD = int(rng.choice([63, 64, 65, 100, 126, 127, 128, 129, 191, 192, 255, int(rng.integers(63, 128)), int(rng.integers(63, 300))]))
             seed = int(rng.integers(0, 1 << 30))
             L, R, _ = make_pair(H, W, max(2, min(numD, W) // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
             if rng.random() < 0.3:
