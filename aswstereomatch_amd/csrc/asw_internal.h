@@ -206,6 +206,9 @@ int launch_planes_to_windows(hipStream_t s, const float* planes, int H, int W, i
 int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL, const uint16_t* wR,
                         int H, int W, int win, int minD, int nD, int flip, float* vol, float* disp, double* partE /* optional
                         scratch [8][H][W] */, float* partD, int c_begin = 0, int out_slice = -1);
+// a few candidates [c_begin, nD) of a 15x15 problem (the remainder behind the xq passes), un-mirrored: imgF / wF = the fixed image
+int launch_asw_geodesic_few(hipStream_t s, const uint32_t* imgF, const uint32_t* imgO, const uint16_t* wF, const uint16_t* wO, int H,
+                            int W, int minD, int c_begin, int nD, bool right, float* vol, double* outE, float* outD);
 // xq form (k_geodesic_xq.hip): one pass = candidates [cbase, cbase + 16 * nwave), nwave = 8 or 4, DISPARITY_LEFT, win = 15
 int geodesic_xq_pass_candidates(int nwave);
 int launch_geodesic_xq(hipStream_t s, hipStream_t s_border, int nwave, const uint32_t* imgL, const uint32_t* imgR, const uint16_t* wL,

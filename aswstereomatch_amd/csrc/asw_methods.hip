@@ -456,7 +456,11 @@ static int run_geodesic(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep
                 cb += geodesic_xq_pass_candidates(nw);
                 ns++;
             }
-        if (cb < nD) {
+        if (cb < nD && nD - cb <= 4) {  // the reference's inclusive range: one candidate behind the passes at numDisparity = 192
+            ASW_TRY(launch_asw_geodesic_few(ctx->aux[1], pf, po, wf, wo, H, W, mp.minD, cb, nD, flip != 0, vol, sE + (size_t)ns * plane,
+                                            sD + (size_t)ns * plane));
+            ns++;
+        } else if (cb < nD) {
             ASW_TRY(launch_asw_geodesic(ctx->aux[1], pf, po, wf, wo, H, W, mp.win, mp.minD, nD, flip, vol, f->disp.as<float>(), sE, sD,
                                         cb, ns));
             ns++;

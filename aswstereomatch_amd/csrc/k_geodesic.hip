@@ -36,11 +36,21 @@ __global__ __launch_bounds__(256) void k_pack_bgrx(const uint8_t* __restrict__ b
 __device__ __forceinline__ uint32_t cdist(uint32_t a, uint32_t b) { return __builtin_amdgcn_sad_u8(a, b, 0u); }
 
 // One thread = one pixel.  WIN is the (odd) window size; planes: [WIN*WIN][H][W] (u16 or f32).
+// The backward sweep can only reach the cells above the centre and those left of it in its own row: every cell below the centre row
+// (and right of the centre in it) still holds FLT_MAX when the forward sweep starts.  So the backward sweep runs rows h+1 .. 1
+// only, and only those (h+1) * WIN intermediate values are kept for the forward sweep -- in LDS (u16, one column of 64 lanes
+// per cell: 15 KB per wavefront at 15x15) when they fit in 16 KB, else in the output planes themselves.  Every plane is then
+// written ONCE, after the forward sweep (the first version stored all 225 planes after the backward sweep, read them back and
+// stored them again: 1.9 GB of traffic for 0.42 GB of tables at KITTI size).
 template <int WIN, typename OutT>
 __global__ __launch_bounds__(64) void k_geodesic_weights(const uint32_t* __restrict__ img, int H, int W, int backward,
                                                          int forward, OutT* __restrict__ planes)
 {
     constexpr int h = WIN / 2, N = WIN + 2;
+    constexpr int NKEEP = (h + 1) * WIN;
+    constexpr bool KEEP_LDS = NKEEP * 64 * 2 <= 16 * 1024;
+    __shared__ uint16_t skeep[KEEP_LDS ? NKEEP * 64 : 1];
+    const int lane = threadIdx.x;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
@@ -54,18 +64,28 @@ __global__ __launch_bounds__(64) void k_geodesic_weights(const uint32_t* __restr
         else o = v >= GEO_INF ? 3.402823466e+38f : (float)v;
         planes[(size_t)((r - 1) * WIN + (c - 1)) * plane + pix] = o;
     };
+    // intermediate value of cell (r, c), r <= h + 1, between the sweeps (distances are below 65535 for windows up to 35x35)
+    auto keep = [&](int r, int c, uint32_t v) {
+        if constexpr (KEEP_LDS) skeep[((r - 1) * WIN + (c - 1)) * 64 + lane] = (uint16_t)(v >= GEO_INF ? 65535u : v);
+        else store(r, c, v);
+    };
+    auto kept = [&](int r, int c) -> uint32_t {
+        if constexpr (KEEP_LDS) {
+            const uint32_t o = skeep[((r - 1) * WIN + (c - 1)) * 64 + lane];
+            return o == 65535u ? GEO_INF : o;
+        } else {
+            const OutT o = planes[(size_t)((r - 1) * WIN + (c - 1)) * plane + pix];
+            if constexpr (sizeof(OutT) == 2) return (o == 65535u) ? GEO_INF : (uint32_t)o;
+            else return (o > 1e30f) ? GEO_INF : (uint32_t)o;
+        }
+    };
 
-    // ---- backward sweep: r = WIN..1, c = WIN..1; neighbours R, BR, B, BL (M.cpp:1367-1387) ----
+    // ---- backward sweep: r = h+1..1 (the rows below stay FLT_MAX), c = WIN..1; neighbours R, BR, B, BL (M.cpp:1367-1387) ----
     uint32_t dprev[N], pprev[N];  // distances / pixels of row r+1
 #pragma unroll
-    for (int c = 0; c < N; c++) dprev[c] = GEO_INF;  // ring row WIN+1 (M.cpp:1416)
-    {
-        const uint32_t* row = img + (size_t)reflect_idx(y + h + 1, H) * W;
-#pragma unroll
-        for (int c = 0; c < N; c++) pprev[c] = row[col[c]];
-    }
+    for (int c = 0; c < N; c++) { dprev[c] = GEO_INF; pprev[c] = 0u; }  // row h+2: all FLT_MAX, its pixels never matter
     if (backward) {
-        for (int r = WIN; r >= 1; r--) {
+        for (int r = h + 1; r >= 1; r--) {
             uint32_t dcur[N], pcur[N];
             const uint32_t* row = img + (size_t)reflect_idx(y - h - 1 + r, H) * W;
 #pragma unroll
@@ -81,50 +101,57 @@ __global__ __launch_bounds__(64) void k_geodesic_weights(const uint32_t* __restr
                 v = min(v, dprev[c - 1] + cdist(pprev[c - 1], pcur[c])); // BL
                 v = min(v, GEO_INF);                                      // FLT_MAX + d == FLT_MAX
                 dcur[c] = v;
-                store(r, c, v);
+                if (forward) keep(r, c, v);
+                else store(r, c, v);
             }
 #pragma unroll
             for (int c = 0; c < N; c++) { dprev[c] = dcur[c]; pprev[c] = pcur[c]; }
         }
     } else {
-        for (int r = WIN; r >= 1; r--)
+        for (int r = h + 1; r >= 1; r--)
 #pragma unroll
-            for (int c = WIN; c >= 1; c--) store(r, c, (r == h + 1 && c == h + 1) ? 0u : GEO_INF);
+            for (int c = WIN; c >= 1; c--) {
+                const uint32_t v = (r == h + 1 && c == h + 1) ? 0u : GEO_INF;
+                if (forward) keep(r, c, v);
+                else store(r, c, v);
+            }
+    }
+    if (!forward) {  // fewer than three iterations: the rows below the centre keep their initial FLT_MAX
+        for (int r = h + 2; r <= WIN; r++)
+#pragma unroll
+            for (int c = 1; c <= WIN; c++) store(r, c, GEO_INF);
+        return;
     }
 
     // ---- forward sweep: r = 1..WIN, c = 1..WIN; neighbours L, UL, U, UR (M.cpp:1343-1362) ----
-    if (forward) {
 #pragma unroll
-        for (int c = 0; c < N; c++) dprev[c] = GEO_INF;  // ring row 0
-        {
-            const uint32_t* row = img + (size_t)reflect_idx(y - h - 1, H) * W;
+    for (int c = 0; c < N; c++) dprev[c] = GEO_INF;  // ring row 0
+    {
+        const uint32_t* row = img + (size_t)reflect_idx(y - h - 1, H) * W;
 #pragma unroll
-            for (int c = 0; c < N; c++) pprev[c] = row[col[c]];
+        for (int c = 0; c < N; c++) pprev[c] = row[col[c]];
+    }
+    for (int r = 1; r <= WIN; r++) {
+        uint32_t dcur[N], pcur[N];
+        const uint32_t* row = img + (size_t)reflect_idx(y - h - 1 + r, H) * W;
+#pragma unroll
+        for (int c = 0; c < N; c++) pcur[c] = row[col[c]];
+        dcur[0] = GEO_INF;
+        dcur[N - 1] = GEO_INF;
+        const bool upper = r <= h + 1;  // wave-uniform
+#pragma unroll
+        for (int c = 1; c <= WIN; c++) {
+            uint32_t v = upper ? kept(r, c) : GEO_INF;
+            v = min(v, dcur[c - 1] + cdist(pcur[c - 1], pcur[c]));   // L
+            v = min(v, dprev[c - 1] + cdist(pprev[c - 1], pcur[c])); // UL
+            v = min(v, dprev[c] + cdist(pprev[c], pcur[c]));         // U
+            v = min(v, dprev[c + 1] + cdist(pprev[c + 1], pcur[c])); // UR
+            v = min(v, GEO_INF);
+            dcur[c] = v;
+            store(r, c, v);
         }
-        for (int r = 1; r <= WIN; r++) {
-            uint32_t dcur[N], pcur[N];
-            const uint32_t* row = img + (size_t)reflect_idx(y - h - 1 + r, H) * W;
 #pragma unroll
-            for (int c = 0; c < N; c++) pcur[c] = row[col[c]];
-            dcur[0] = GEO_INF;
-            dcur[N - 1] = GEO_INF;
-#pragma unroll
-            for (int c = 1; c <= WIN; c++) {
-                OutT o = planes[(size_t)((r - 1) * WIN + (c - 1)) * plane + pix];
-                uint32_t v;
-                if constexpr (sizeof(OutT) == 2) v = (o == 65535u) ? GEO_INF : (uint32_t)o;
-                else v = (o > 1e30f) ? GEO_INF : (uint32_t)o;
-                v = min(v, dcur[c - 1] + cdist(pcur[c - 1], pcur[c]));   // L
-                v = min(v, dprev[c - 1] + cdist(pprev[c - 1], pcur[c])); // UL
-                v = min(v, dprev[c] + cdist(pprev[c], pcur[c]));         // U
-                v = min(v, dprev[c + 1] + cdist(pprev[c + 1], pcur[c])); // UR
-                v = min(v, GEO_INF);
-                dcur[c] = v;
-                store(r, c, v);
-            }
-#pragma unroll
-            for (int c = 0; c < N; c++) { dprev[c] = dcur[c]; pprev[c] = pcur[c]; }
-        }
+        for (int c = 0; c < N; c++) { dprev[c] = dcur[c]; pprev[c] = pcur[c]; }
     }
 }
 
@@ -331,6 +358,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
+// A FEW candidates (the remainder of a range cut into xq passes: one candidate at the reference's numDisparity = 192, whose range
+// is inclusive) on the un-mirrored problem: thread = one pixel, the 225 taps in a loop, both weight planes streamed once per
+// candidate (coalesced u16 rows), the BGRX pixels from two LDS tiles.  The chunked kernel above spent 0.74 ms and 0.83 GB on that
+// one candidate (a 16-wide chunk machinery around one lane of work); this is bound by reading the two 210 MB tables once.
+//   fixed / other: the image the disparity map belongs to / the other one (LEFT: left / right), sgn = -1 (LEFT: q = max(0, x - d))
+//   or +1 (RIGHT: q = min(W-1, x + d))                                                         (M.cpp:1467-1496, 1498-1520)
+template <int WIN>
+__global__ __launch_bounds__(256) void k_asw_geodesic_few(const uint32_t* __restrict__ imgF, const uint32_t* __restrict__ imgO,
+                                                          const uint16_t* __restrict__ wF, const uint16_t* __restrict__ wO, int H, int W,
+                                                          int minD, int c_begin, int c_end, int sgn, float* __restrict__ vol,
+                                                          double* __restrict__ outE, float* __restrict__ outD)
+{
+    constexpr int h = WIN / 2, TR = TH + 2 * h, LW = TW + 2 * h;
+    __shared__ uint32_t sF[TR * LW], sO[TR * LW];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x = x0 + tx, y = y0 + ty, xc = min(x, W - 1), yc = min(y, H - 1);
+    const size_t plane = (size_t)H * W;
+    for (int i = tid; i < TR * LW; i += 256) {
+        const int r = i / LW, c = i - r * LW;
+        sF[i] = imgF[(size_t)min(max(y0 - h + r, 0), H - 1) * W + min(max(x0 - h + c, 0), W - 1)];
+    }
+    double bestE = 1.7976931348623157e308;
+    float bestD = 0.0f;
+    for (int cand = c_begin; cand < c_end; cand++) {
+        const int d = minD + cand;
+        __syncthreads();  // previous candidate's tile is dead (and sF is complete)
+        for (int i = tid; i < TR * LW; i += 256) {
+            const int r = i / LW, c = i - r * LW;
+            // the other image's sample of window column nx = clamp(x0 - h + c): column max(0, nx - d) / min(W-1, nx + d)
+            const int nx = min(max(x0 - h + c, 0), W - 1);
+            const int ox = min(max(nx + sgn * d, 0), W - 1);
+            sO[i] = imgO[(size_t)min(max(y0 - h + r, 0), H - 1) * W + ox];
+        }
+        __syncthreads();
+        const int q = min(max(xc + sgn * d, 0), W - 1);
+        const uint16_t* pf = wF + (size_t)yc * W + xc;
+        const uint16_t* po = wO + (size_t)yc * W + q;
+        double num = 0.0, den = 0.0;
+        for (int j = 0; j < WIN; j++)
+#pragma unroll
+            for (int i = 0; i < WIN; i++) {
+                const size_t cell = (size_t)(j * WIN + i) * plane;
+                const float wl = (float)pf[cell], wr = (float)po[cell];
+                const float c = (float)cdist(sF[(ty + j) * LW + tx + i], sO[(ty + j) * LW + tx + i]);
+                const float ab = wl * wr;   // f32
+                const float abc = ab * c;   // f32 (M.cpp:1488-1490)
+                num = num + (double)abc;    // exact integers: any order
+                den = den + (double)ab;
+            }
+        if (x < W && y < H) {
+            const double E = num / den;  // 0/0 -> NaN for windows flat in both images (App. B-9)
+            if (vol) vol[((size_t)cand * H + y) * W + x] = (float)E;
+            if (E < bestE) { bestE = E; bestD = (float)d; }
+        }
+    }
+    if (x < W && y < H) {
+        outE[(size_t)y * W + x] = bestE;
+        outD[(size_t)y * W + x] = bestD;
+    }
+}
+
 template <int WIN, typename OutT>
 int launch_weights_t(hipStream_t s, const uint32_t* img, int H, int W, int backward, int forward, OutT* planes)
 {
@@ -423,4 +512,16 @@ int launch_asw_geodesic(hipStream_t s, const uint32_t* imgL, const uint32_t* img
     // 16-wide d-chunks: 25 KB of LDS at win 15 (45 KB at win 35)
     if (geo_lds_bytes<16>(win) <= 160 * 1024) return launch_geo_t<16>(s, p, imgL, imgR, wL, wR, vol, disp, partE, partD);
     return ASW_ERR_BAD_ARGUMENT;
+}
+
+// candidates [c_begin, nD) of a 15x15 problem, winners to outE / outD ([H][W]); imgF / wF: the fixed image and its weight planes
+int launch_asw_geodesic_few(hipStream_t s, const uint32_t* imgF, const uint32_t* imgO, const uint16_t* wF, const uint16_t* wO, int H,
+                            int W, int minD, int c_begin, int nD, bool right, float* vol, double* outE, float* outD)
+{
+    if (c_begin < 0 || c_begin >= nD || !outE || !outD) return ASW_ERR_BAD_ARGUMENT;
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH);
+    hipLaunchKernelGGL(k_asw_geodesic_few<15>, grid, dim3(256), 0, s, imgF, imgO, wF, wO, H, W, minD, c_begin, nD, right ? 1 : -1, vol,
+                       outE, outD);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
 }
