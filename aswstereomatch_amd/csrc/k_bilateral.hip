@@ -226,6 +226,12 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
             sWL[t * (TH * TW) + tid] = wlv[t];
         }
         if (doB) *dstB = wb;
+        // The hardware orders them; the COMPILER must be told that other lanes read these words (to one thread its store and the
+        // loads of its neighbours' slots never alias, so it may delay or sink the store: k_guided.hip ran into exactly that).
+        // Wavefront-scope fences cost no instruction.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (g0 + G < p.ntaps) gather(g0 + G);  // in flight while this group is accumulated
         // rolled on purpose: one tap's operands (1 + 4 + DC registers) live at a time keeps the kernel at
         // <= 128 VGPRs, i.e. 4 waves per SIMD, which hides the LDS latency better than deeper unrolling did
@@ -245,6 +251,10 @@ __device__ __forceinline__ void process_chunk(const BilParams& p, const uint8_t*
                 den[dd] = den[dd] + abd;                            // M.cpp:1107-1108
             }
         }
+        // the next group's stores stay behind this group's loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
     const int x = x0 + tx, y = y0 + ty;
