@@ -1,16 +1,17 @@
 // Guided-filter aggregation (getGuidedFilter, M.cpp:2766-2854) and the box-mean machinery it is made of.
 //
 // boxFilter(CV_32F, Size(k,k), normalised, BORDER_REFLECT_101) == f64 window sum * 1/(k*k) -> f32
-// (SURVEY App. A-9).  One generic "column walk" kernel evaluates NP box means at once:
-//   * a wavefront owns 64 input columns (64-(k-1) output columns) of a band of rows and walks down the
-//     band; every lane keeps NP vertical running sums in f64 (add the entering row, subtract the leaving
-//     one -- the same sliding form as OpenCV's ColumnSum; the leaving row is recomputed from cached loads);
-//   * per output row the vertical sums go through a wave-private LDS strip (no workgroup barrier) and each
-//     output column adds its k neighbours in ascending order (conflict-free ds_read_b64);
-//   * the producer (Src) and consumer (Dst) are functors, so normalisation, products, covariance,
-//     a = cov/(var+eps), b and q are fused into the filters that need them and never hit HBM as
-//     separate planes.
-// The kernels are bound by f64 VALU + HBM streaming of the a/b planes, see DESIGN.md.
+// (SURVEY App. A-9).  One generic "column walk" kernel (k_box_walk) evaluates NP box means at once:
+//   * a wavefront owns a strip of 128 input columns (two adjacent ones per lane; 128-(k-1) output columns) of a band of rows
+//     and walks down the band; every lane keeps NP vertical running sums in f64 (add the entering row, subtract the leaving
+//     one -- the sliding form of OpenCV's ColumnSum);
+//   * the leaving row comes from a register ring of the last 15 rows' operands (RING: the 3-channel guided filter at 15x15)
+//     or is fetched again (every other launch);
+//   * per output row the vertical sums go through a wave-private LDS strip (no workgroup barrier, wavefront-scope fences
+//     for the compiler) and every lane adds the neighbours of its two output columns;
+//   * the producer (Src) and consumer (Dst) are functors, so normalisation, products, covariance, a = cov/(var+eps), b and q
+//     are fused into the filters that need them and never hit HBM as separate planes.
+// Layouts, variants and what bounds the launches: DESIGN.md 4.2 (rounds 1-2) and 4.2c (round 3).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -30,8 +31,8 @@ template <class D> struct DstRawSel<D, true> { using type = typename D::Raw2; };
 // Every wavefront owns a strip of 128 input columns (two adjacent ones per lane, 128-(k-1) output columns)
 // of a band of rows and walks down the band on its own:
 //   * vertical running sums in f64 registers (add the entering row, subtract the leaving one -- ColumnSum's
-//     sliding form; the leaving row is re-fetched from cache rather than kept: an LDS ring cost 61 KB per
-//     workgroup and 2x the run time);
+//     sliding form; the leaving row is re-fetched from cache or kept in a REGISTER ring (RING, below): an LDS ring cost
+//     61 KB per workgroup and 2x the run time);
 //   * horizontal sums through a wave-private LDS strip: LDS operations of one wavefront execute in order, so
 //     no workgroup barrier is needed; a lane's second column reuses the first one's sum (- b[0] + b[k]).
 //   * ND slices per wavefront: operands that do not depend on the slice (guide pixel, guide statistics) are
@@ -436,7 +437,6 @@ struct StatsSplit {
 // box(I_c), box(I_c*I_c) -> meanI_c, den_c = (corrI_c - meanI_c^2) + eps      (M.cpp:2778, 2796-2799, 2846)
 template <int C, int W0, bool SHIFT>  // W0: which BGRX word (channels 3*W0 .. 3*W0+2) this launch covers
 struct StatsSrc {
-    static const char* band_env() { return "ASW_BAND_STATS"; }
     GuideAccT<SHIFT> g;
     typedef typename GuideAccT<SHIFT>::Col Col;
     struct Raw { uint32_t u[C / 3]; };
@@ -523,12 +523,11 @@ __global__ void k_scale_groups(const float2* __restrict__ scales, int n, int* __
 template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
 
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
-// KEEPG: the register ring keeps the guide word(s) next to the cost (C/3 + 1 dwords per column and row); otherwise the cost
-// only, and the guide pixel of the leaving row is fetched again (slice-independent: an L1 / L2 hit)
-template <int C, bool SHIFT, bool KEEPG = true>
+// The register ring keeps the cost and the guide word(s) of a row: C/3 + 1 dwords per column and row.  (Keeping the cost only and
+// fetching the leaving row's guide word again saves 30 registers and a wavefront per SIMD, and measured 0.3-0.4 ms slower.)
+template <int C, bool SHIFT>
 struct ABSrc {
-    static const char* band_env() { return "ASW_BAND_AB"; }
-    static constexpr int KEEP = KEEPG ? C / 3 + 1 : 1;
+    static constexpr int KEEP = C / 3 + 1;
     GuideAccT<SHIFT> g;
     const float* P;          // raw cost volume [n][H][W]
     const float2* pscales;   // per-slice normalize() parameters
@@ -546,24 +545,16 @@ struct ABSrc {
     __device__ __forceinline__ void keep(const Raw& r, uint32_t (&w)[KEEP]) const
     {
         w[0] = __float_as_uint(r.p);
-        if constexpr (KEEPG) {
 #pragma unroll
-            for (int i = 0; i < C / 3; i++) w[1 + i] = r.u[i];
-        }
+        for (int i = 0; i < C / 3; i++) w[1 + i] = r.u[i];
     }
-    struct LRaw { uint32_t u[KEEPG ? 1 : C / 3]; };  // the guide word(s) of the leaving row when the ring holds the cost only
-    __device__ __forceinline__ LRaw leave_fetch(int yo, const Col& c) const
-    {
-        LRaw l;
-        if constexpr (KEEPG) l.u[0] = 0;
-        else g.template fetch<C / 3>(yo, c.g, l.u);
-        return l;
-    }
-    __device__ __forceinline__ Raw leave(const uint32_t (&w)[KEEP], const LRaw& l) const
+    typedef NoRaw LRaw;
+    __device__ __forceinline__ LRaw leave_fetch(int, const Col&) const { return LRaw(); }
+    __device__ __forceinline__ Raw leave(const uint32_t (&w)[KEEP], const LRaw&) const
     {
         Raw r;
 #pragma unroll
-        for (int i = 0; i < C / 3; i++) r.u[i] = KEEPG ? w[KEEPG ? 1 + i : 0] : l.u[KEEPG ? 0 : i];
+        for (int i = 0; i < C / 3; i++) r.u[i] = w[1 + i];
         r.p = __uint_as_float(w[0]);
         return r;
     }
@@ -653,7 +644,6 @@ struct ABDst {
 // box(a_c), box(b) -> q = sum_c box(a_c)*I_c + box(b)                           (M.cpp:2849-2852)
 template <int C>
 struct QSrc {
-    static const char* band_env() { return "ASW_BAND_Q"; }
     const float* ab;
     int H, W;
     static constexpr int AS = ABStride<C>::value;
@@ -899,7 +889,6 @@ struct ABDstP {
 };
 // box(a_c), box(b) from the planar a/b volume                                                              (M.cpp:2849-2850)
 struct QSrcP {
-    static const char* band_env() { return "ASW_BAND_Q"; }
     const float2* ab;  // strip-major tiles, see ABTiles
     ABTiles at;
     struct Col { const float2* p; };
@@ -969,7 +958,6 @@ struct QDstP {
 
 // getCostSAD_d (M.cpp:2442-2503): |grayL - grayR shifted| as f32, box mean
 struct SadSrc {
-    static const char* band_env() { return "ASW_BAND_SAD"; }
     const uint8_t* gl;
     const uint8_t* gr;
     int W, minD, disp_type;
@@ -995,7 +983,6 @@ struct SadSrc {
 };
 // plain 8U plane as f32 (boxFilter(8U -> CV_32F) of getInputImgNCC, M.cpp:785-786)
 struct U8Src {
-    static const char* band_env() { return "ASW_BAND_U8"; }
     const uint8_t* img;
     int W;
     struct Col { const uint8_t* p; };
@@ -1103,10 +1090,10 @@ int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>&
     if (ring_ab) {  // ring = {cost, guide word} of the last 15 rows of both columns: 2 wavefronts per SIMD
         // (the ring holding the cost only and the leaving row's guide word fetched again -- 3 wavefronts per SIMD -- measured
         // 0.3-0.4 ms slower: two more loads per step in a pass whose address unit is as busy as its VALU)
-        ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
+        ABSrc<3, SHIFT> src{g, a.P, a.pscales, a.H, a.W};
         rc = launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
     } else {
-        ABSrc<3, SHIFT, true> src{g, a.P, a.pscales, a.H, a.W};
+        ABSrc<3, SHIFT> src{g, a.P, a.pscales, a.H, a.W};
         rc = a.nan_safe ? launch_walk_t<4, 2, 1, 3, true>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab)
                         : launch_walk_t<4, 2, 1, 3, false>(s, src, dst, a.H, a.W, a.r, a.n, -1, oab);
     }
