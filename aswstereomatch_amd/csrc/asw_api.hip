@@ -398,8 +398,8 @@ extern "C" int asw_guided_filter(asw_ctx* ctx, const asw_image* guide, const flo
     ASW_TRY(stats.ensure(guided_stats_floats(C, 1, H, W) * 4));
     ASW_TRY(ab.ensure(guided_ab_floats(C, 1, H, W, r) * 4));
     ASW_TRY(qv.ensure(plane * 4));
-    ASW_TRY(pxa.ensure(plane * 4));
-    ASW_TRY(pxb.ensure(plane * 4));
+    ASW_TRY(pxa.ensure((plane + 4) * 4));  // + slack: the q pass reads the guide words of a lane's two columns as one pair, the last one may start at column W-1
+    ASW_TRY(pxb.ensure((plane + 4) * 4));
     ASW_TRY(launch_pack_words(ctx->stream, dg.as<uint8_t>(), H, W, C, 0, pxa.as<uint32_t>()));
     if (C == 6) ASW_TRY(launch_pack_words(ctx->stream, dg.as<uint8_t>(), H, W, C, 1, pxb.as<uint32_t>()));
     ASW_HIP_TRY(hipMemcpyAsync(raw.p, p, plane * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -325,8 +325,8 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     ASW_TRY(gsc.ensure((size_t)n * sizeof(float2)));
     ASW_TRY(stats.ensure(guided_stats_floats(C, nstat, H, W) * 4));
     ASW_TRY(ab.ensure(guided_ab_floats(C, n, H, W, mp.win) * 4));
-    ASW_TRY(pxa.ensure(plane * 4));
-    ASW_TRY(pxb.ensure(plane * 4));
+    ASW_TRY(pxa.ensure((plane + 4) * 4));  // + slack: the q pass reads the guide words of a lane's two columns as one pair, the last one may start at column W-1
+    ASW_TRY(pxb.ensure((plane + 4) * 4));
     ASW_TRY(f->vol.ensure(plane * n * 4));  // q volume: always needed for the WTA pass
     ASW_TRY(f->disp.ensure(plane * 4));
     f->vol_floats = keep_volume ? plane * n : 0;

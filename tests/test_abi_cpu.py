@@ -73,3 +73,23 @@ def test_volume_planes_is_a_pure_host_function():
     l = _lib.lib()
     assert [l.asw_volume_planes(a, 64) for a in range(12)] == [0, 0, 65, 65, 65, 65, 64, 64, 64, 64, 64, 64]
     assert l.asw_volume_planes(99, 64) == 0
+
+
+def test_algorithmic_bytes_is_one_function_for_bench_and_tools():
+    """B_alg = 2*W*H*3 + W*H*N_d*4 + W*H*4 with N_d = D+1 for the inclusive ranges; bench.py and tools/pmc_traffic.py
+    import the same function, and the committed counter records carry the value it gives for their shape."""
+    import json
+
+    from aswstereomatch_amd.roofline import algorithmic_bytes, candidates
+
+    assert algorithmic_bytes(1920, 1080, candidates(8, 128)) == 1082419200      # C3
+    assert algorithmic_bytes(1920, 1080, candidates(2, 128)) == 1090713600      # C5 frame
+    assert algorithmic_bytes(1242, 375, candidates(4, 192)) == 364216500        # C4
+    for name, alg in (("bilateral", 2), ("guided2", 8), ("geodesic", 4)):
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % name)))
+        W, H, D, _ = rec["shape"]
+        assert rec["algorithmic_bytes_per_frame"] == algorithmic_bytes(W, H, candidates(alg, D))
+        assert rec["hbm_bytes_per_frame"] == sum(k["fetch_bytes_corrected"] + k["write_bytes"] for k in rec["per_kernel"].values()) or \
+            abs(rec["hbm_bytes_per_frame"] - sum(k["fetch_bytes_corrected"] + k["write_bytes"] for k in rec["per_kernel"].values())) < 64
+    import bench
+    assert bench.algorithmic_bytes is algorithmic_bytes

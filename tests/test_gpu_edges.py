@@ -344,3 +344,26 @@ def test_padded_host_rows_in_and_out(ctx, oracle):
     ui, _keep2 = _image(u8big[:, :W])
     assert ctx._lib.asw_download_disparity_u8(ctx._h, 3, C.byref(ui), 0) == 0
     assert np.array_equal(u8big[:, :W], oracle.disparity_to_u8(want, False)) and (u8big[:, W:] == 9).all()
+
+
+# ---------------------------------------------------------------- the library reads its switches once, in asw_create
+def test_switches_are_read_once_at_context_creation(oracle):
+    """ASW_BILATERAL_XQ & co. are measurement / test switches: asw_create reads them, no call does.  A context
+    created under a switch keeps it after the environment changed back, and a context created without it ignores a later setenv;
+    the results are the same either way (both kernel forms are bit-identical), only the launch count tells them apart."""
+    import os
+
+    L, R, _ = make_pair(6, 200, 100, seed=4, block=16)
+    rc, want, _ = oracle.asw_classic(L, R, 30, 20, 0, 15, 0, 128)
+    forced = asw.Context(0, env={"ASW_BILATERAL_XQ": "0"})       # the variable exists only while asw_create runs
+    assert "ASW_BILATERAL_XQ" not in os.environ
+    plain = asw.Context(0)
+    os.environ["ASW_BILATERAL_XQ"] = "0"                          # too late for `plain`
+    try:
+        for c, launches in ((forced, 1), (plain, 4)):
+            assert np.array_equal(c.computeAdaptiveWeight(L, R, 30, 20, LEFT, 15, 0, 128), want)
+            assert c.timing()["aggregate_launches"] == launches
+    finally:
+        del os.environ["ASW_BILATERAL_XQ"]
+        forced.close()
+        plain.close()
