@@ -280,6 +280,38 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 #pragma unroll
                 for (int n = 0; n < ND; n++) {
                     float m[CPL][NP];
+                    if constexpr (PAIRS && RING) {
+                        // All LDS reads of a group of planes are issued before the first addition (the scheduler, left alone,
+                        // orders them plane by plane to save registers: ~16 exposed LDS round trips per step, and at two
+                        // wavefronts per SIMD nobody hides them -- one wavefront alone spent two thirds of a step waiting).
+                        constexpr int HP = (KT - 1) / 2;
+                        constexpr int GRP = 2;  // planes whose reads are in flight together (16 registers each; all four: spills)
+#pragma unroll
+                        for (int p0 = 0; p0 < NP; p0 += GRP) {
+                            double bb[GRP][2 * HP + 2];
+#pragma unroll
+                            for (int g = 0; g < GRP; g++)
+                                if (p0 + g < NP) {
+                                    const double* b = hs + (n * NP + p0 + g) * (SW + 2) + c0;
+#pragma unroll
+                                    for (int i = 2; i < 2 * HP + 2; i++)
+                                        if (!(i & 1) || i == 2 * HP + 1) bb[g][i] = b[i];  // pair sums of lanes l+1 .. l+HP, V[even] of l+HP
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int g = 0; g < GRP; g++)
+                                if (p0 + g < NP) {
+                                    const int p = p0 + g;
+                                    double t = bb[g][2];
+#pragma unroll
+                                    for (int i = 2; i < HP; i++) t = t + bb[g][2 * i];
+                                    const double s0 = ((vs[0][n][p] + vs[1][n][p]) + t) + bb[g][2 * HP + 1];
+                                    const double s1 = (vs[1][n][p] + t) + bb[g][2 * HP];
+                                    m[0][p] = (float)(s0 * scale);
+                                    m[1][p] = (float)(s1 * scale);
+                                }
+                        }
+                    } else
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const double* b = hs + (n * NP + p) * (SW + 2) + c0;
@@ -344,13 +376,26 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     using T = std::true_type;
     using F = std::false_type;
     int s = 0, ph = 0;
+    // The FIFO slot of a step is a compile-time phase, and the loops are unrolled by the number of slots: a run-time dispatch on
+    // the phase inside the loop (if (ph == 0) ... else ...) makes the compiler copy the FIFO registers at the join, and those
+    // copies WAIT for the loads issued at the top of the very same step -- the pipeline then hides one step's arithmetic, not
+    // its depth in steps.
     auto run = [&](int s_end, auto sub_c, auto out_c) {
-        for (; s < s_end; s++) {
-            if (ph == 0) step(s, std::integral_constant<int, 0>(), sub_c, out_c);
-            if constexpr (NPH > 1) { if (ph == 1) step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); }
-            if constexpr (NPH > 2) { if (ph == 2) step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); }
-            if constexpr (NPH > 3) { if (ph == 3) step(s, std::integral_constant<int, 3 % NPH>(), sub_c, out_c); }
-            ph = ph + 1 == NPH ? 0 : ph + 1;
+        // seams as straight-line code (a loop around a run-time phase dispatch costs hundreds of spilled registers):
+        // up to NPH-1 steps until the phase is 0, the unrolled loop, up to NPH-1 steps behind it
+        if constexpr (NPH > 1) { if (ph == 1 && s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2 % NPH; } }
+        if constexpr (NPH > 2) { if (ph == 2 && s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); s++; ph = 3 % NPH; } }
+        if constexpr (NPH > 3) { if (ph == 3 && s < s_end) { step(s, std::integral_constant<int, 3 % NPH>(), sub_c, out_c); s++; ph = 0; } }
+        if (ph == 0) {
+            for (; s + NPH <= s_end; s += NPH) {  // NPH steps, every FIFO slot a fixed set of registers
+                step(s, std::integral_constant<int, 0>(), sub_c, out_c);
+                if constexpr (NPH > 1) step(s + 1, std::integral_constant<int, 1 % NPH>(), sub_c, out_c);
+                if constexpr (NPH > 2) step(s + 2, std::integral_constant<int, 2 % NPH>(), sub_c, out_c);
+                if constexpr (NPH > 3) step(s + 3, std::integral_constant<int, 3 % NPH>(), sub_c, out_c);
+            }
+            if constexpr (NPH > 1) { if (s < s_end) { step(s, std::integral_constant<int, 0>(), sub_c, out_c); s++; ph = 1; } }
+            if constexpr (NPH > 2) { if (s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2; } }
+            if constexpr (NPH > 3) { if (s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); s++; ph = 3; } }
         }
     };
     run(min(k - 1, steps), F(), F());
@@ -1102,7 +1147,8 @@ int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>&
     auto run_q = [&](const auto& qd) {
         // ring = {a_0, a_1, a_2, b} of the last 15 rows of both columns (128 registers): 2 wavefronts per SIMD.  One column per lane
         // (4 wavefronts) measured 2.75 ms against 1.7: twice the wavefront-rows through the one LDS of the CU
-        if (ring_q) return launch_walk_t<4, 2, 1, 2, false, 1, 1>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
+        // loads two steps ahead: 1.61 ms against 1.72 at one step (three: 1.58 with spilled registers)
+        if (ring_q) return launch_walk_t<4, 2, 1, 2, false, 1, 2>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
         return a.nan_safe ? launch_walk<4, 1, true>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq) : launch_walk<4>(s, qs, qd, a.H, a.W, a.r, a.n, -1, oq);
     };
     if constexpr (SHIFT) {
