@@ -38,6 +38,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "asw_internal.h"
 
@@ -61,7 +62,7 @@ constexpr int LW8 = 80;                   // u8 row stride of the left tile (mul
 // LDS layout (bytes): double [KS][LWC] left gray | double [KS][RWC] right gray | float [RING][KS][PXW] left weights |
 // float [2][KS][NPOS] right weights | u8 [KS][LW8] | u8 [KS][RW8] | u16 [NCELLCOL * KS] packed cell table.
 // Epilogue (over the dead tiles): double [NFIN][PXW] E | per-part WTA partials double E[NW][PXW], float d[NW][PXW].
-// NW = 8: 81 280 B, two workgroups = 16 wavefronts per CU; NW = 4: 62 KB, two workgroups = 8 wavefronts per CU.
+// NW = 8: 81 280 B, two workgroups = 16 wavefronts per CU; NW = 4: 52 KB (f32 gray tiles), three workgroups = 12 wavefronts per CU.
 template <int NW>
 struct XqCfg {
     static constexpr int NWAVE = NW;
@@ -72,9 +73,13 @@ struct XqCfg {
     static constexpr int NFIN = 4 * NJ;
     static constexpr int RW8 = (RWC + 3) / 4 * 4;
     static constexpr int NROWS = (KS + NW - 1) / NW;  // window rows a wavefront stages
+    // Gray tiles for the cost samples: f64 (NW = 8: nothing is converted in the row loop), f32 for NW = 4 -- 13 KB less, 52 KB in
+    // all, so that THREE workgroups (12 wavefronts) fit a CU instead of two, for 7 v_cvt_f64_f32 per row step (the differences of
+    // two gray bytes are exact in f32)
+    static constexpr int GB = NW == 8 ? 8 : 4;
     static constexpr int OFF_LD = 0;
-    static constexpr int OFF_RD = OFF_LD + KS * LWC * 8;
-    static constexpr int OFF_WL = OFF_RD + KS * RWC * 8;
+    static constexpr int OFF_RD = (OFF_LD + KS * LWC * GB + 15) / 16 * 16;
+    static constexpr int OFF_WL = (OFF_RD + KS * RWC * GB + 15) / 16 * 16;
     static constexpr int OFF_WR = OFF_WL + RING * KS * PXW * 4;
     static constexpr int OFF_L8 = OFF_WR + 2 * KS * NPOS * 4;
     static constexpr int OFF_R8 = OFF_L8 + KS * LW8;
@@ -82,7 +87,8 @@ struct XqCfg {
     static constexpr int LDS_TOTAL = (OFF_CELL + NCELLCOL * KS * 2 + 15) / 16 * 16;
     static constexpr int OFF_E64 = 0;
     static constexpr int OFF_PART = NFIN * PXW * 8;
-    static_assert(LDS_TOTAL <= 80 * 1024, "two workgroups per CU");
+    typedef typename std::conditional<NW == 8, double, float>::type GrayT;
+    static_assert(LDS_TOTAL <= (NW == 8 ? 80 : 53) * 1024, "two (NW = 8) / three (NW = 4) workgroups per CU");
     static_assert(OFF_PART + NW * PXW * 12 <= LDS_TOTAL, "epilogue buffers fit in the dead tiles");
     static_assert(OFF_RD % 16 == 0 && OFF_WL % 16 == 0 && OFF_WR % 16 == 0 && (KS * NPOS * 4) % 16 == 0 && (NPOS * 4) % 16 == 0, "b128 alignment");
     static_assert(NPOS % 64 == 0, "positions are staged in whole wavefront passes");
@@ -200,8 +206,9 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
     constexpr int BLO = K > KS - 1 ? K - (KS - 1) : 0;  // kx = K - b <= 14
     constexpr int BHI = K < 3 ? K : 3;                  // kx = K - b >= 0
     constexpr int DLO = 0 - BHI, DHI = 3 - BLO;         // diagonals a - b in use
-    const double* sLd = reinterpret_cast<const double*>(smem + OFF_LD);
-    const double* sRd = reinterpret_cast<const double*>(smem + OFF_RD);
+    typedef typename Cfg::GrayT GrayT;
+    const GrayT* sLd = reinterpret_cast<const GrayT*>(smem + OFF_LD);
+    const GrayT* sRd = reinterpret_cast<const GrayT*>(smem + OFF_RD);
     const float* sWL = reinterpret_cast<const float*>(smem + OFF_WL);
     const float* sWR = reinterpret_cast<const float*>(smem + OFF_WR) + (K & 1) * (KS * NPOS);
 
@@ -217,9 +224,9 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
             iR[dl + 3] = min(max(rc - (posmin - HH), 0), RWC - 1);
         }
     }
-    const double* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
-    const double* pr = sRd + qrel + K;    // tile column of Q + K - 7
-    const double* pr2 = sRd + qrel2 + K;
+    const GrayT* pl = sLd + 4 * g + K;   // + dl: tile column of x + dl + K - 7
+    const GrayT* pr = sRd + qrel + K;    // tile column of Q + K - 7
+    const GrayT* pr2 = sRd + qrel2 + K;
     const float* pwl = sWL + 4 * g;
     const float* pwr = sWR + qrel;
     const float* pwr2 = sWR + qrel2;
@@ -230,23 +237,23 @@ __device__ __forceinline__ void run_step(unsigned char* smem, int g, int qrel, i
         }
         double c[7];
         if constexpr (!EDGE) {
-            const double gr = pr[ky * RWC];
-            double gr2 = gr;
+            const GrayT gr = pr[ky * RWC];
+            GrayT gr2 = gr;
             if constexpr (WRAPW && (RIGHT ? DHI > 0 : DLO < 0)) gr2 = pr2[ky * RWC];
             // the left grays of the step, read as 16-byte aligned pairs from an even tile column (4g, LWC and E0 are even): a
             // run that starts on an odd column is split by the compiler into ds_read2_b64, which cost four times the LDS cycles
             // of ds_read_b128 here (8 instead of 4, and 2-way conflicts: their banks are taken mod 32)
             constexpr int E0 = (K + DLO) & ~1, NP2 = (K + DHI - E0 + 2) / 2;
-            typedef double f64x2 __attribute__((ext_vector_type(2)));
-            const f64x2* pl2 = reinterpret_cast<const f64x2*>(sLd + 4 * g + E0 + ky * LWC);
-            double glv[2 * NP2];
+            typedef GrayT gx2 __attribute__((ext_vector_type(2)));
+            const gx2* pl2 = reinterpret_cast<const gx2*>(sLd + 4 * g + E0 + ky * LWC);
+            GrayT glv[2 * NP2];
 #pragma unroll
-            for (int i = 0; i < NP2; i++) { const f64x2 t = pl2[i]; glv[2 * i] = t.x; glv[2 * i + 1] = t.y; }
+            for (int i = 0; i < NP2; i++) { const gx2 t = pl2[i]; glv[2 * i] = t.x; glv[2 * i + 1] = t.y; }
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = glv[K + dl - E0] - ((RIGHT ? dl > 0 : dl < 0) ? gr2 : gr);
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = (double)(glv[K + dl - E0] - ((RIGHT ? dl > 0 : dl < 0) ? gr2 : gr));  // exact in f32 too
         } else {
 #pragma unroll
-            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]];
+            for (int dl = DLO; dl <= DHI; dl++) c[dl + 3] = (double)(sLd[ky * LWC + iL[dl + 3]] - sRd[ky * RWC + iR[dl + 3]]);
         }
         const float4 wr4 = *reinterpret_cast<const float4*>(pwr + ky * NPOS);
         const float wr[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
@@ -295,7 +302,7 @@ __device__ __forceinline__ void run_all_steps(unsigned char* smem, const float* 
 // bestE / bestD: [H][W] running minimum over candidates [0, NFIN) (strict '<' in ascending d, M.cpp:1145-1150) for the tail
 // launch to resume from; disp (when there is no tail): the disparity itself.
 template <int NW, bool EDGE, int ABL, bool RIGHT>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void k_asw_bilateral_xq(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_asw_bilateral_xq(
     XqParams p, const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, const int4* __restrict__ cells,
     const float* __restrict__ lut, float* __restrict__ vol, double* __restrict__ bestE, float* __restrict__ bestD,
     float* __restrict__ disp)
@@ -313,21 +320,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
     {
         uint8_t* sL8 = smem + OFF_L8;
         uint8_t* sR8 = smem + OFF_R8;
-        double* sLd = reinterpret_cast<double*>(smem + OFF_LD);
-        double* sRd = reinterpret_cast<double*>(smem + OFF_RD);
+        typedef typename Cfg::GrayT GrayT;
+        GrayT* sLd = reinterpret_cast<GrayT*>(smem + OFF_LD);
+        GrayT* sRd = reinterpret_cast<GrayT*>(smem + OFF_RD);
         for (int i = tid; i < KS * LWC; i += NTHR) {
             const int r = i / LWC, c = i - r * LWC;
             const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(x0 - HH + c, 0), W - 1);
             const int v = gL[(size_t)yy * W + xx];
             sL8[r * LW8 + c] = (uint8_t)v;
-            sLd[r * LWC + c] = (double)v;
+            sLd[r * LWC + c] = (GrayT)v;
         }
         for (int i = tid; i < KS * RWC; i += NTHR) {
             const int r = i / RWC, c = i - r * RWC;
             const int yy = min(max(y - HH + r, 0), H - 1), xx = min(max(posmin - HH + c, 0), W - 1);
             const int v = gR[(size_t)yy * W + xx];
             sR8[r * RW8 + c] = (uint8_t)v;
-            sRd[r * RWC + c] = (double)v;
+            sRd[r * RWC + c] = (GrayT)v;
         }
         uint16_t* sCell = reinterpret_cast<uint16_t*>(smem + OFF_CELL);
         for (int i = tid; i < NCELLCOL * KS; i += NTHR) {
