@@ -36,17 +36,19 @@ __global__ __launch_bounds__(256) void k_scharr_x(const uint8_t* __restrict__ im
 // differences (exact integers, so the float sums/differences of the reference are exact too).
 // tCi = floor(thresC): for an integer colour, (double)colour > thresC  <=>  colour > floor(thresC);
 // tGdn = largest float <= thresG: for a float g, (double)g > thresG  <=>  g > tGdn.
-__device__ __forceinline__ float similarity_pixel(int c01, int c2, int g01i, int g2i, float rr, float rg, float thresCf,
-                                                  int tCi, float tGdn, float thresGf)
+// colour term times (1 - regularity), a function of s = min(255, c0+c1) + c2 in [0, 510] only: tabulated per workgroup
+__device__ __forceinline__ float similarity_colour(int s, float rr, float thresCf, int tCi)
 {
     // colour term (u8): (c0+c1+c2)/3 -> round((min(255,c0+c1)+c2)/3); >thresC ? min(255, v+thresC) : 0  (M.cpp:459-465)
-    int t = min(255, c01);
-    int color = (t + c2 + 1) / 3;
+    int color = (s + 1) / 3;
     int maskC = (color > tCi) ? 1 : 0;
     float tf = (float)(color * maskC) * 1.0f + 255.0f * (float)maskC * thresCf;  // addWeighted(m1,1,mask,thresC/255)
     int cc_i = __float2int_rn(tf);                                                 // cvRound: to nearest even
     cc_i = min(255, max(0, cc_i));
-    float cc = (float)cc_i;
+    return (float)cc_i * rr;                            // first product of addWeighted(cc, 1-reg, cg, reg), M.cpp:484
+}
+__device__ __forceinline__ float similarity_gradient(int g01i, int g2i, float rg, float tGdn, float thresGf)
+{
     // gradient term (f32): (g0+g1+g2)/3 = addWeighted(g0+g1, 1/3, g2, 1/3)   (M.cpp:473)
     const float third = (float)(1.0 / 3.0);
     float g01 = (float)g01i, g2 = (float)g2i;
@@ -55,9 +57,8 @@ __device__ __forceinline__ float similarity_pixel(int c01, int c2, int g01i, int
     float bit = (float)maskG, bit_not = (float)(255 - maskG);  // bitwise_not of a 0/1 mask: 255/254 (App. B-6)
     float gm = g * bit;
     float cg = bit_not * thresGf + gm;                  // scaleAdd(bit_not, thresG, gm)     (M.cpp:482)
-    return cc * rr + cg * rg;                           // addWeighted(cc, 1-reg, cg, reg)   (M.cpp:484)
+    return cg * rg;                                     // second product of the addWeighted
 }
-
 // ---- min/max reductions ------------------------------------------------------------------
 // order-preserving map float -> uint so that integer atomics give float min/max (any sign)
 __device__ __forceinline__ uint32_t f2ord(float f)
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ 
     const int u0 = x0 - (minD + ke - 1);  // u = x - offset: leftmost shifted column this chunk touches
     uint32_t* sC = sim_smem;                                            // [SIM_ROWS][WLp] B | G<<8 | R<<16
     uint2* sG = reinterpret_cast<uint2*>(sim_smem + SIM_ROWS * WLp);     // [SIM_ROWS][WLp] {g0 | g1<<16, g2}
+    // the colour term depends on s = min(255, |a0-b0| + |a1-b1|) + |a2-b2| only: 511 values, evaluated once per workgroup with the
+    // very expression a pixel would use (15 of the ~35 instructions per output become one LDS read)
+    float* sLut = reinterpret_cast<float*>(sim_smem + SIM_ROWS * WLp * 3);
+    for (int i = tid; i < 511; i += 256) sLut[i] = similarity_colour(i, rr, thresCf, tCi);
     for (int i = tid; i < SIM_ROWS * WL; i += 256) {
         const int r = i / WL, j = i - r * WL;
         const int y = min(y0 + r, H - 1), u = u0 + j;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void k_similarity(const uint8_t* __restrict__ 
                 const int c2 = (int)__builtin_amdgcn_sad_u8(a2[r], b >> 16, 0u);
                 const int g01 = abs(ga0[r] - (int)(short)(gb.x & 0xffffu)) + abs(ga1[r] - ((int)gb.x >> 16));
                 const int g2 = abs(ga2[r] - (int)gb.y);
-                const float v = similarity_pixel(c01, c2, g01, g2, rr, rg, thresCf, tCi, tGdn, thresGf);
+                const float v = sLut[min(255, c01) + c2] + similarity_gradient(g01, g2, rg, tGdn, thresGf);
                 if (x < W) {
                     cost[((size_t)k * H + (y0 + r)) * W + x] = v;
                     const uint32_t o = f2ord(v);
@@ -354,10 +359,10 @@ int launch_similarity(hipStream_t s, const uint8_t* L, const uint8_t* R, const s
     const int nz = (numD + dch - 1) / dch, chunk = numD < dch ? numD : dch;
     dim3 grid((W + 255) / 256, (H + SIM_ROWS - 1) / SIM_ROWS, nz);
     const int WLp = (256 + chunk - 1 + 1) & ~1;
-    const size_t lds = (size_t)SIM_ROWS * WLp * 12;
+    const size_t lds = (size_t)SIM_ROWS * WLp * 12 + 512 * 4;  // tiles + the colour-term table
     float rr = (float)(1.0 - regularity), rg = (float)regularity;  // regularityR, M.cpp:435
     float thresCf = (float)(thresC * (1.0 / 255.0));
-    // integer / float forms of the two double comparisons (see similarity_pixel)
+    // integer / float forms of the two double comparisons (see similarity_colour / similarity_gradient)
     double fc = floor(thresC);
     int tCi = fc < -1.0 ? -1 : (fc > 1e6 ? 1000000 : (int)fc);
     float tGdn = (float)thresG;
