@@ -14,3 +14,13 @@ for (H, W, D, win) in [(1080, 1920, 64, 15), (1080, 1920, 100, 15), (360, 640, 6
             best = min(best, c.timing()["aggregate_ms"])
         print("%dx%d D=%d win=%d %-22s aggregate %.3f ms  launches %d" % (W, H, D, win, env or "default", best, c.timing()["aggregate_launches"]), flush=True)
         c.close()
+# the 35x35 stress point of SURVEY 8d (1080p, D=128)
+L, R, _ = make_pair(1080, 1920, 128, seed=1)
+c = asw.Context(0)
+c.upload_pair(0, L, R)
+best = 1e9
+for i in range(2):
+    c.match_resident(0, 0, 2, 35, 0, 128, keep_volume=True)
+    best = min(best, c.timing()["aggregate_ms"])
+print("1920x1080 D=128 win=35 aggregate %.3f ms" % best, flush=True)
+c.close()
