@@ -924,8 +924,10 @@ struct ABDstP {
         ab_of(Rb, mb, m1, o1);
         const size_t row = (size_t)y * at.TW;
         if (second) {
-            *reinterpret_cast<float4*>(c.ab + row) = make_float4(o0[0], o0[1], o1[0], o1[1]);
-            *reinterpret_cast<float4*>(c.ab + at.plane + row) = make_float4(o0[2], o0[3], o1[2], o1[3]);
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f va = {o0[0], o0[1], o1[0], o1[1]}, vb = {o0[2], o0[3], o1[2], o1[3]};
+            __builtin_nontemporal_store(va, reinterpret_cast<v4f*>(c.ab + row));            // written once, read by the next launch:
+            __builtin_nontemporal_store(vb, reinterpret_cast<v4f*>(c.ab + at.plane + row)); // keep it from displacing the statistics in L2
         } else {
             c.ab[row] = make_float2(o0[0], o0[1]);
             c.ab[at.plane + row] = make_float2(o0[2], o0[3]);
@@ -996,8 +998,13 @@ struct QDstP {
     {
         const float q0 = q_of(r.u.x, c, m0), q1 = q_of(r.u.y, c, m1);
         float* o = c.q + (size_t)y * W;
-        if (second) *reinterpret_cast<float2*>(o) = make_float2(q0, q1);
-        else o[0] = q0;
+        if (second) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f v = {q0, q1};
+            __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(o));  // streamed out, read again only by the WTA sweep
+        } else {
+            o[0] = q0;
+        }
     }
 };
 
