@@ -373,7 +373,12 @@ __global__ __launch_bounds__(256) void k_asw_geodesic_few(const uint32_t* __rest
     constexpr int h = WIN / 2, TR = TH + 2 * h, LW = TW + 2 * h;
     __shared__ uint32_t sF[TR * LW], sO[TR * LW];
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    // every XCD takes a contiguous run of tiles (see k_asw_geodesic_xq): a tile row is 128 bytes of a u16 weight plane at an
+    // arbitrary alignment, i.e. two 128-byte lines, each shared with a neighbour -- dealt round-robin, the neighbours sat on
+    // other XCDs and every line came from HBM twice (0.82 GB fetched for 0.42 GB of tables)
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, vid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+    const int x0 = (vid % (int)gridDim.x) * TW, y0 = (vid / (int)gridDim.x) * TH;
     const int x = x0 + tx, y = y0 + ty, xc = min(x, W - 1), yc = min(y, H - 1);
     const size_t plane = (size_t)H * W;
     for (int i = tid; i < TR * LW; i += 256) {

@@ -230,7 +230,13 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ __align__(16) unsigned char smem[G::LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
-    const int x0 = (p.tile0 + blockIdx.x) * PXW, y = blockIdx.y;
+    // Workgroups are dealt round-robin over the 8 XCDs in launch order.  Give every XCD a CONTIGUOUS run of (row, tile) pairs
+    // instead: the 64 workgroups an XCD has in flight are then neighbouring tiles of a few rows, whose right-image positions
+    // overlap (188 positions per 64 pixels) and whose weight-table lines are fetched from HBM once and hit in that XCD's L2
+    // afterwards.  In launch order the tiles of an XCD were 512 pixels apart: every workgroup fetched its own 113 KB.
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, vid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+    const int x0 = (p.tile0 + vid % (int)gridDim.x) * PXW, y = vid / (int)gridDim.x;
     const int posmin = RIGHT ? x0 + p.d0 : x0 - p.d0 - 4 * G::NJ;
     const size_t plane = (size_t)H * W;
 
