@@ -76,6 +76,7 @@ void AswTuning::read_environment()
     wmedian_tile = num("ASW_WMEDIAN_TILE", wmedian_tile);
     wmedian_tile_chunk = num("ASW_WMEDIAN_TILE_CHUNK", wmedian_tile_chunk);
     wmedian_tile_split = num("ASW_WMEDIAN_TILE_SPLIT", wmedian_tile_split);
+    wmedian_gen_rows = num("ASW_WMEDIAN_GEN_ROWS", wmedian_gen_rows);
     band_ab = num("ASW_BAND_AB", band_ab);
     band_q = num("ASW_BAND_Q", band_q);
     ring_ab = num("ASW_RING_AB", ring_ab);

@@ -64,6 +64,7 @@ struct AswTuning {
     int wmedian_tile = -1;       // ASW_WMEDIAN_TILE: 0 = per-pixel sort (k_wmedian)
     int wmedian_tile_chunk = 0;  // ASW_WMEDIAN_TILE_CHUNK: slices per list chunk (tests: odd chunkings)
     int wmedian_tile_split = 0;  // ASW_WMEDIAN_TILE_SPLIT: workgroups per pixel block
+    int wmedian_gen_rows = 0;    // ASW_WMEDIAN_GEN_ROWS: block rows per workgroup of the general tile form (windows 17..37): 1 | 2 | 4 | 8
     int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
     int ring_ab = 1, ring_q = 1; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_guided3), 0 = re-fetch
     int q_wg_strips = 1;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
@@ -222,6 +223,11 @@ int launch_wmedian(hipStream_t s, const float* cost, const float* wLd, const flo
 size_t wmedian_tile_list_slots(int H, int W, int d_count);
 int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int numD, int max_off,
                         int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int nsplit /* A/B: AswTuning */);
+// windows 17x17 .. 37x37 (k_wmedian_tile_gen.hip)
+bool wmedian_tile_gen_supported(int win);
+int wmedian_tile_gen_slots(int win);
+int launch_wmedian_tile_gen(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD,
+                            int max_off, int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int rows_per_part);
 
 // ---- O(1)-bilateral ASW (BLO1), k_blo1.hip ----
 int launch_blo1(hipStream_t s, const uint8_t* gl, const uint8_t* gr, const float* cost, int step, int H, int W, int disp_type,

@@ -548,7 +548,7 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     ASW_TRY(launch_wm_weights(ctx->stream, dL, H, W, 0, mp.win, ctx->wm_lut2.as<float>(), ctx->wm_wd.as<float>(), wl.as<float>()));
     ASW_TRY(launch_wm_weights(ctx->stream, dR, H, W, max_off, mp.win, ctx->wm_lut2.as<float>(), nullptr, wr.as<float>()));
     // 15x15 (the reference's call site): the neighbourhood of an 8x8 pixel block is sorted once per slice and every pixel walks
-    // it (k_wmedian_tile.hip); other windows sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
+    // it (k_wmedian_tile.hip); 17x17 .. 37x37 likewise (below); other windows sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
     // (3 KB per block and slice) below 2 GiB.  ASW_WMEDIAN_TILE=0 forces the per-pixel sort (A/B measurements, tests).
     if (mp.win == 15 && ctx->tune.wmedian_tile != 0) {
         const size_t per_slice = wmedian_tile_list_slots(H, W, 1);
@@ -562,6 +562,20 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
             ASW_TRY(launch_wmedian_tile(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, n, max_off, d0,
                                         std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>(),
                                         ctx->tune.wmedian_tile_split));
+    } else if (wmedian_tile_gen_supported(mp.win) && ctx->tune.wmedian_tile != 0) {
+        // 17x17 .. 37x37: the same scheme with the window a run-time parameter (k_wmedian_tile_gen.hip), 6 or 12 KB of list per
+        // block and slice
+        const size_t per_slice = wmedian_tile_list_slots(H, W, 1) / 512 * (size_t)wmedian_tile_gen_slots(mp.win);
+        int chunk = (int)std::min<size_t>((size_t)n, std::max<size_t>(8, (((size_t)2 << 30) / 6 / per_slice) / 8 * 8));
+        if (ctx->tune.wmedian_tile_chunk > 0) chunk = std::max(1, std::min(n, ctx->tune.wmedian_tile_chunk));
+        DevBuf& lc = ctx->buf("wmListC");
+        DevBuf& lp = ctx->buf("wmListP");
+        ASW_TRY(lc.ensure(per_slice * chunk * 4));
+        ASW_TRY(lp.ensure(per_slice * chunk * 2));
+        for (int d0 = 0; d0 < n; d0 += chunk)
+            ASW_TRY(launch_wmedian_tile_gen(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off, d0,
+                                            std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>(),
+                                            ctx->tune.wmedian_gen_rows));
     } else
         ASW_TRY(launch_wmedian(ctx->stream, raw.as<float>(), wl.as<float>(), wr.as<float>(), H, W, mp.win, n, max_off,
                                f->vol.as<float>()));
