@@ -119,8 +119,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 // A part = rpp rows of the 8x8 block; wavefront w takes the slices d_begin + w, w + NW, ... of the chunk.
 // LDS (dynamic): float sWL[8 * rpp][wls] | float sWR[NW][wls] | u16 sT[win * 64 + 1]   (wls = win^2 + 1 rounded up to 4, slot
 // win^2 = 0: "not in this window").
-template <int KPL, int NW>
-__global__ __launch_bounds__(64 * NW) void k_wmg_pick(const float* __restrict__ wLd /* [H][W][n] */, const float* __restrict__ wRb /* [H][Wb][n] */,
+template <int KPL, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_wmg_pick(const float* __restrict__ wLd /* [H][W][n] */, const float* __restrict__ wRb /* [H][Wb][n] */,
                                                       const uint32_t* __restrict__ listC, const uint16_t* __restrict__ listP, int H, int W,
                                                       int win, int nbx, int nparts, int rpp, int numD, int max_off, int d_begin,
                                                       int d_count, float* __restrict__ out /* [numD][H][W] */)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void k_wmg_pick(const float* __restrict__ 
     }
 }
 
-template <int KPL, int NW>
+template <int KPL, int NW, int WPE>
 int launch_t(hipStream_t s, const float* cost, const float* wLd, const float* wRb, int H, int W, int win, int numD, int max_off,
              int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int rpp)
 {
@@ -269,7 +269,7 @@ int launch_t(hipStream_t s, const float* cost, const float* wLd, const float* wR
                        d_count, listC, listP);
     const int NC = win * win, wls = (NC + 1 + 3) & ~3, nparts = BH / rpp;
     const size_t lds = ((size_t)(BW * rpp + NW) * wls) * 4 + (((size_t)win * 64 + 1) * 2 + 15) / 16 * 16;
-    auto kern = k_wmg_pick<KPL, NW>;
+    auto kern = k_wmg_pick<KPL, NW, WPE>;
     if (lds > 160 * 1024) return ASW_ERR_BAD_ARGUMENT;
     if (lds > 64 * 1024)
         ASW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -296,6 +296,8 @@ int launch_wmedian_tile_gen(hipStream_t s, const float* cost, const float* wLd, 
     const bool small = wmedian_tile_gen_slots(win) == 1024;
     int rpp = rows_per_part;
     if (rpp != 1 && rpp != 2 && rpp != 4 && rpp != 8) rpp = small ? 2 : 1;
-    if (small) return launch_t<16, 8>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
-    return launch_t<32, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
+    if (small) return launch_t<16, 8, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
+    // 2048 slots: 180 registers, two workgroups of four wavefronts per CU (2 x 63 KB of LDS at 35x35).  Two workgroups of SIX
+    // wavefronts at a register target of 168 (three per SIMD, 10 registers spilled): 201 against 158 ms at 35x35, 152 / 132 at 27x27.
+    return launch_t<32, 4, 2>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
 }

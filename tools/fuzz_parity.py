@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
                     "both directions, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
+    ap.add_argument("--wmbig", type=float, default=0.0, help="share of the cases forced to the weighted median at 17x17 .. 41x41 (general tile form, k_wmedian_tile_gen.hip; per-pixel sort above 37)")
     ap.add_argument("--wm15", type=float, default=0.0, help="share of the cases forced to the 15x15 weighted median (the tile form, k_wmedian_tile.hip)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -88,6 +89,16 @@ def main():
         if rng.random() < args.wm15:
             method, win, dt = "wmedian", 15, 0
             numD = int(rng.integers(1, 40))
+        if rng.random() < args.wmbig:
+            method, win, dt = "wmedian", int(rng.choice([17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37, 39, 41])), 0
+            H, W, numD = int(rng.integers(1, 36)), int(rng.integers(1, 90)), int(rng.integers(1, 20))
+            minD = int(rng.choice([0, 0, 1, 4]))
+            seed = int(rng.integers(0, 1 << 30))
+            L, R, _ = make_pair(H, W, max(2, min(numD, W) // 2), seed=seed, block=int(rng.choice([4, 8, 16])))
+            if rng.random() < 0.3:  # flat rectangles: ties
+                for img in (L, R):
+                    y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                    img[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 40))] = rng.integers(0, 256, 3).astype(np.uint8)
         tag = (method, H, W, win, minD, numD, dt, seed)
         if args.fresh_every > 0 and n > 0 and n % args.fresh_every == 0:
             ctx.close()
@@ -176,10 +187,14 @@ def main():
                 got, bad = ctx.leftRightCheck(a, b, tau, -1.0)
                 ok = np.array_equal(got, want) and bad == wbad
             elif method == "wmedian":
-                if win > 17:  # the general path (64-bit keys, 512 / 1024 / 2048 slots): small frames only
+                if win > 37:  # per-pixel sort (64-bit keys, 2048 slots): small frames only
                     H2, W2 = min(H, 14), min(W, 40)
                     L, R = np.ascontiguousarray(L[:H2, :W2]), np.ascontiguousarray(R[:H2, :W2])
                     numD = min(numD, 6)
+                elif win > 17:  # general tile form; the oracle's multimap per (pixel, d) sets the size
+                    H2, W2 = min(H, 24), min(W, 64)
+                    L, R = np.ascontiguousarray(L[:H2, :W2]), np.ascontiguousarray(R[:H2, :W2])
+                    numD = min(numD, 10)
                 rs, rr = [(10, 10), (5, 20), (3, 3), (25, 2.5)][int(rng.integers(0, 4))]
                 rc, dw, vw = O.asw_wmedian(L, R, 0, win, rs, rr, minD, numD, want_vol=True)
                 d, v = ctx.computeAdaptiveWeight_WeightedMedian(L, R, 0, win, rs, rr, minD, numD, return_cost_volume=True)
