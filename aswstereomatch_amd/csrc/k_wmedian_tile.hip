@@ -47,9 +47,13 @@ __global__ __launch_bounds__(256) void k_wm_sort_regions(const float* __restrict
                                                          uint16_t* __restrict__ listP)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int dd = blockIdx.y * 4 + wv;
+    // every XCD takes a contiguous run of (slice group, block) pairs: neighbouring blocks' regions overlap (22 of 8 columns /
+    // rows) and share 128-byte lines of the cost plane, which then come from HBM once
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, vid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+    const int dd = (vid / (int)gridDim.x) * 4 + wv;
     if (dd >= d_count) return;  // whole wavefront
-    const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
+    const int blk = vid % (int)gridDim.x, by = blk / nbx, bx = blk - by * nbx;
     const int x0 = bx * BW, y0 = by * BH;
     const float* cp = cost + (size_t)(d_begin + dd) * H * W;
     LaneMasks lm;
@@ -147,7 +151,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
-// grid (blocks, NSPLIT), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, the 64 / NSPLIT pixels
+// grid blocks * NSPLIT (one dimension, see the mapping below), 512 threads: wavefront w takes the slices d_begin + w, w + 8, ... and, for each, the 64 / NSPLIT pixels
 // (whole rows of the block) of this workgroup's part.  NSPLIT = 2 halves the LDS weight slab: four workgroups per CU.
 // COMPACT (NSPLIT = 4, two pixel rows per part): the windows of the part cover 16 of the region's 22 rows, so each wavefront
 // first drops the entries of the other rows from its list (a prefix-sum scatter through LDS that keeps the sorted order):
@@ -167,12 +171,17 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
     __shared__ uint32_t sC[COMPACT ? PICK_WAVES : 1][COMPACT ? 64 * KE : 1];  // compaction buffer (original slot << 16 | position)
     static_assert(!COMPACT || NSPLIT == 4, "the compacted list holds the 16 region rows of a two-row part");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
+    // one-dimensional grid of (block, part) pairs; every XCD takes a contiguous run of them, so the parts of a block -- which
+    // read the same sorted lists -- run on one XCD at about the same time and the lists come from HBM once, not once per part
+    const int nwg = gridDim.x, lin = blockIdx.x;
+    const int xcd = lin & 7, vid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+    const int blk = vid / NSPLIT, part = vid - blk * NSPLIT;
+    const int by = blk / nbx, bx = blk - by * nbx;
     const int x0 = bx * BW, y0 = by * BH;
     const int Wb = W + max_off;
     const size_t plane = (size_t)H * W;
 
-    const int p_begin = blockIdx.y * NPART;
+    const int p_begin = part * NPART;
     if (y0 + (p_begin >> 3) >= H) return;  // this part lies below the image (whole workgroup)
     for (int i = tid; i < NPART * WLS; i += 64 * PICK_WAVES) {
         const int p = p_begin + i / WLS, c = i % WLS;
@@ -330,13 +339,13 @@ int launch_wmedian_tile(hipStream_t s, const float* cost, const float* wLd, cons
     const dim3 blk(64 * PICK_WAVES);
     const unsigned nb = (unsigned)(nbx * nby);
     if (nsplit == 1)
-        hipLaunchKernelGGL((k_wm_pick<1, false>), dim3(nb, 1), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<1, false>), dim3(nb * 1), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     else if (nsplit == 2)
-        hipLaunchKernelGGL((k_wm_pick<2, false>), dim3(nb, 2), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<2, false>), dim3(nb * 2), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     else if (nsplit == 4)
-        hipLaunchKernelGGL((k_wm_pick<4, false>), dim3(nb, 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<4, false>), dim3(nb * 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     else
-        hipLaunchKernelGGL((k_wm_pick<4, true>), dim3(nb, 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
+        hipLaunchKernelGGL((k_wm_pick<4, true>), dim3(nb * 4), blk, 0, s, wLd, wRb, listC, listP, H, W, nbx, numD, max_off, d_begin, d_count, out);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }

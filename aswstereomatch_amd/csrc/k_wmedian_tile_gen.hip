@@ -37,10 +37,13 @@ __global__ __launch_bounds__(256) void k_wmg_sort(const float* __restrict__ cost
 {
     constexpr int SLOTS = 64 * KPL;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int dd = blockIdx.y * 4 + wv;
+    // every XCD takes a contiguous run of (slice group, block) pairs: neighbouring regions overlap and share lines of the cost plane
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, vid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+    const int dd = (vid / (int)gridDim.x) * 4 + wv;
     if (dd >= d_count) return;  // whole wavefront
     const int hw = win / 2, RW = BW + win - 1, nreg = RW * (BH + win - 1);
-    const int blk = blockIdx.x, by = blk / nbx, bx = blk - by * nbx;
+    const int blk = vid % (int)gridDim.x, by = blk / nbx, bx = blk - by * nbx;
     const int x0 = bx * BW, y0 = by * BH;
     const float* cp = cost + (size_t)(d_begin + dd) * H * W;
     LaneMasks lm;
