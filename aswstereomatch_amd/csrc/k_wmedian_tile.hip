@@ -9,9 +9,10 @@
 //   1. k_wm_sort_regions: one wavefront sorts the region of a (block, d) once (512 slots, 8 per lane, f64 keys
 //      = cost bits * 1024 + region index: exact integers, compare-exchange = v_min_f64 / v_max_f64) -> list in memory;
 //   2. k_wm_pick: a wavefront takes the list of a (block, d) (8 entries per lane, in sorted order) and, for each of the 64
-//      pixels, turns every entry into (member of this pixel's window ? weight : 0) -- a byte table maps the entry's
-//      position relative to the pixel to the window cell or to a zero slot, the weights wL*wd (per pixel, in LDS for the
-//      whole block) and wR (row of 225, staged per pixel) are gathered by cell -- then forms the f64 prefix sums in sorted
+//      pixels, turns every entry into (member of this pixel's window ? weight : -0.0) -- the pixel's 225 weights
+//      (wL*wd, in LDS for the whole block, times wR, a row of 225 fetched per pixel) are written into a layout indexed by
+//      position relative to the window, so an entry gathers its weight at (its position - the pixel's) with one LDS read;
+//      every slot that is no window cell holds -0.0 (adds nothing, and marks "not a member") -- then forms the f64 prefix sums in sorted
 //      order (8 per lane + a DPP wavefront scan), finds the first prefix above half of the total (M.cpp:3284-3291) and
 //      returns the cost of the last member before it (or of the crossing element itself if it is the first, :3293-3301).
 // No per-pixel sort: ~9 instructions per list entry and pixel instead of a 36-step network per pixel.
@@ -34,14 +35,16 @@ constexpr int SLOTS = 512, KPL = 8;
 constexpr uint32_t COST_BASE_BITS = 0x45800000u;  // 4096.0f: every TAD C+G cost lies in [4096, 16384) (k_wmedian.hip)
 constexpr uint32_t POS_PAD = 1023u;               // position of the 28 padding slots: never inside a window
 constexpr double KEY_PAD = 4398046511104.0;       // 2^42: above every real key (cost bits < 2^24, * 1024)
-constexpr int WLS = NC + 1;                       // per-pixel weight row + the zero slot (cell 225 = "not in this window")
-constexpr int WRS = 228;                          // staged right row + zero slot, padded
-constexpr int NT = 481;                           // relative position -> cell table: 15 rows x 32 + the clamp slot
+constexpr int WLS = NC + 1;                       // per-pixel weight row (+1: odd stride)
+constexpr int PS = 47;                            // row stride of a position (row * 47 + column): 47 = 32 + 15, so the 64 consecutive window cells a
+                                                  // wavefront writes at once (15 per row) fall into consecutive LDS banks
+constexpr int LAY = WIN * PS + 1;                 // a pixel's weights laid out BY RELATIVE POSITION: 15 rows x 47 + the clamp slot
+static_assert((RH - 1) * PS + RW - 1 < 1023, "positions stay below the padding position");
 constexpr int PICK_WAVES = 8;
 
 // ---- 1. sort the 22 x 22 cost region of every (block, d) --------------------------------------------------------------------
 // grid (blocks, ceil(d_count / 4)), 256 threads: wavefront w sorts slice d_begin + 4 * blockIdx.y + w.
-// listC / listP: [block][d_count][512] sorted cost bits / positions (row << 5 | column inside the region).
+// listC / listP: [block][d_count][512] sorted cost bits / positions (row * 47 + column inside the region).
 __global__ __launch_bounds__(256) void k_wm_sort_regions(const float* __restrict__ cost /* [numD][H][W] */, int H, int W, int nbx,
                                                          int d_begin, int d_count, uint32_t* __restrict__ listC,
                                                          uint16_t* __restrict__ listP)
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void k_wm_sort_regions(const float* __restrict
             const int ey = e / RW, ex = e - ey * RW;
             // the window's sample at the REFLECT-padded position (M.cpp:665, 3273)
             const float c = cp[(size_t)reflect_idx(y0 - HW + ey, H) * W + reflect_idx(x0 - HW + ex, W)];
-            key[r] = (double)(__float_as_uint(c) - COST_BASE_BITS) * 1024.0 + (double)(ey * 32 + ex);
+            key[r] = (double)(__float_as_uint(c) - COST_BASE_BITS) * 1024.0 + (double)(ey * PS + ex);
         } else {
             key[r] = KEY_PAD + (double)e;
         }
@@ -164,12 +167,15 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
                                                              float* __restrict__ out /* [numD][H][W] */)
 {
     constexpr int NPART = NPIX / NSPLIT;
-    __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels, slot 225 = 0
-    __shared__ float sWR[PICK_WAVES][WRS];    //  7 296 B: weights of the pixel a wavefront is working on at its d, slot 225 = 0
-    __shared__ uint16_t sT[NT + 1];           // relative position -> byte offset of the cell in a weight row (900 = zero slot)
+    __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels
+    // 22 592 B: the weights of the pixel a wavefront is working on at its d, laid out by position RELATIVE to the window's first
+    // cell (t = dy * 47 + dx + 7): a list entry gathers its weight with ONE LDS read at (its position - the pixel's), no table
+    // in between.  Every slot that is not a window cell holds -0.0f: adding it changes no sum (x + -0.0 = x), and its bit
+    // pattern says "not a member" (a weight product is never -0.0: both factors are >= +0).
+    __shared__ float sWR[PICK_WAVES][LAY];
     constexpr int KE = COMPACT ? 6 : KPL;     // list entries per lane in the walk
-    __shared__ uint32_t sC[COMPACT ? PICK_WAVES : 1][COMPACT ? 64 * KE : 1];  // compaction buffer (original slot << 16 | position)
     static_assert(!COMPACT || NSPLIT == 4, "the compacted list holds the 16 region rows of a two-row part");
+    static_assert(64 * 6 <= LAY, "the compaction buffer (original slot << 16 | position) borrows the wavefront's layout");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // one-dimensional grid of (block, part) pairs; every XCD takes a contiguous run of them, so the parts of a block -- which
     // read the same sorted lists -- run on one XCD at about the same time and the lists come from HBM once, not once per part
@@ -188,14 +194,17 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
         const int x = x0 + (p & 7), y = y0 + (p >> 3);
         sWL[i] = (c < NC && x < W && y < H) ? wLd[((size_t)y * W + x) * NC + c] : 0.0f;
     }
-    for (int i = tid; i < NT; i += 64 * PICK_WAVES) {  // t = dy * 32 + dx + 7 (dx, dy relative to the window's first cell)
-        const int dy = i >> 5, dx = (i & 31) - HW;
-        sT[i] = (uint16_t)(4 * ((i < NT - 1 && dy < WIN && dx >= 0 && dx < WIN) ? dy * WIN + dx : NC));
+    float* wrp = sWR[wv];
+    for (int i = lane; i < LAY; i += 64) wrp[i] = -0.0f;
+    // byte offset of window cell c = lane + 64 k in the layout
+    int coff[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = min(lane + 64 * k, NC - 1), cy = c / WIN;
+        coff[k] = 4 * (cy * PS + (c - cy * WIN) + HW);
     }
-    if (lane < WRS - NC) sWR[wv][NC + lane] = 0.0f;
     __syncthreads();
 
-    float* wrp = sWR[wv];
     unsigned long long vmask = 0;
     for (int q = 0; q < NPART; q++)
         if (x0 + ((p_begin + q) & 7) < W && y0 + ((p_begin + q) >> 3) < H) vmask |= 1ull << q;
@@ -216,10 +225,10 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             int cnt = 0;
 #pragma unroll
             for (int r = 0; r < KPL; r++) {
-                keep[r] = (uint32_t)((pos[r] >> 5) - ly0) < 16u;  // padding entries (row 31) never stay
+                keep[r] = (uint32_t)(pos[r] - ly0 * PS) < 16u * PS;  // rows ly0 .. ly0 + 15; padding entries (position 1023) never stay
                 cnt += keep[r] ? 1 : 0;
             }
-            uint32_t* cb = sC[wv];
+            uint32_t* cb = reinterpret_cast<uint32_t*>(wrp);  // the layout is rebuilt below
 #pragma unroll
             for (int i = 0; i < KE; i++) cb[lane + 64 * i] = POS_PAD;  // slots behind the last kept entry: never a member
             int o = wave_inclusive_scan(cnt) - cnt;
@@ -228,16 +237,22 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
                 if (keep[r]) cb[o] = ((uint32_t)(lane * KPL + r) << 16) | (uint32_t)pos[r];
                 o += keep[r] ? 1 : 0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int i = 0; i < KE; i++) {
                 const uint32_t e = cb[lane * KE + i];
-                epos[i] = 2 * (int)(e & 0xffffu);  // twice the position: the byte offset into the u16 table needs no shift per pixel
+                epos[i] = 4 * (int)(e & 0xffffu);  // four times the position: the byte offset into the layout needs no shift per pixel
                 eslot[i] = e >> 16;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < 64 * KE; i += 64) wrp[i] = -0.0f;  // the borrowed part of the layout: "not a member" again
         } else {
 #pragma unroll
-            for (int i = 0; i < KE; i++) { epos[i] = 2 * pos[i]; eslot[i] = 0; }
+            for (int i = 0; i < KE; i++) { epos[i] = 4 * pos[i]; eslot[i] = 0; }
         }
 
         // right-image weight row of pixel p at this d: weightWinsR[y][x - offset + numDisparity - 1] (M.cpp:3274)
@@ -261,25 +276,31 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             // one cell per lane (conflict-free reads of the pixel's wL row), so that the walk below gathers ONE value per
             // entry: the gathers hit random banks and were what bound the kernel (SQ_LDS_BANK_CONFLICT was half of the LDS cycles)
             const float* wl_row = sWL + (p - p_begin) * WLS;
+            char* wq = reinterpret_cast<char*>(wrp);
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (lane + 64 * k < NC) wrp[lane + 64 * k] = wl_row[lane + 64 * k] * nxt[k];
+                if (lane + 64 * k < NC) *reinterpret_cast<float*>(wq + coff[k]) = wl_row[lane + 64 * k] * nxt[k];
             if (todo) fetch(p_begin + __builtin_ctzll(todo));  // the next pixel's row: in flight under this pixel's arithmetic
+            // LDS operations of a wavefront execute in order; the compiler is told that other lanes read these words
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            const char* wq = reinterpret_cast<const char*>(wrp);
-            const int base7x2 = 2 * ((p >> 3) * 32 + (p & 7) - HW);
+            const int base4 = 4 * ((p >> 3) * PS + (p & 7) - HW);
             double run = 0.0, pre[KE];
             uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit KE - 1 - r
 #pragma unroll
             for (int r = 0; r < KE; r++) {
-                const uint32_t t2 = min((uint32_t)(epos[r] - base7x2), (uint32_t)(2 * (NT - 1)));  // rows above the window wrap to huge values
-                const uint32_t c4 = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(sT) + t2);
-                const float w = *reinterpret_cast<const float*>(wq + c4);  // the cell's weight; 0 outside the window (zero slot)
+                const uint32_t t4 = min((uint32_t)(epos[r] - base4), (uint32_t)(4 * (LAY - 1)));  // rows above the window wrap to huge values
+                const float w = *reinterpret_cast<const float*>(wq + t4);  // the cell's weight; -0.0 outside the window
                 run = r == 0 ? (double)w : run + (double)w;
                 pre[r] = run;
-                mb = (mb << 1) | (c4 != 4u * NC ? 1u : 0u);
+                mb = (mb << 1) | (__float_as_uint(w) != 0x80000000u ? 1u : 0u);
             }
+            // the next pixel's weights overwrite the layout: behind this pixel's gathers
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const double incl = wave_inclusive_scan(run);
             const double half = readlane_f64(incl, 63) * 0.5;  // cv::sum(weight_img_win)[0] / 2, M.cpp:3284
             // first entry whose prefix (exclusive prefix of the lane + local prefix) exceeds half: compared as
