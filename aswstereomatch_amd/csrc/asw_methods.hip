@@ -548,7 +548,7 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
     ASW_TRY(launch_wm_weights(ctx->stream, dL, H, W, 0, mp.win, ctx->wm_lut2.as<float>(), ctx->wm_wd.as<float>(), wl.as<float>()));
     ASW_TRY(launch_wm_weights(ctx->stream, dR, H, W, max_off, mp.win, ctx->wm_lut2.as<float>(), nullptr, wr.as<float>()));
     // 15x15 (the reference's call site): the neighbourhood of an 8x8 pixel block is sorted once per slice and every pixel walks
-    // it (k_wmedian_tile.hip); 17x17 .. 37x37 likewise (below); other windows sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
+    // it (k_wmedian_tile.hip); every other window up to 37x37 likewise (below); 1x1 and 39x39 .. 45x45 sort per pixel (k_wmedian.hip).  Slices go in chunks that keep the sorted lists
     // (3 KB per block and slice) below 2 GiB.  ASW_WMEDIAN_TILE=0 forces the per-pixel sort (A/B measurements, tests).
     if (mp.win == 15 && ctx->tune.wmedian_tile != 0) {
         const size_t per_slice = wmedian_tile_list_slots(H, W, 1);
@@ -563,7 +563,7 @@ static int run_wmedian(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_
                                         std::min(chunk, n - d0), lc.as<uint32_t>(), lp.as<uint16_t>(), f->vol.as<float>(),
                                         ctx->tune.wmedian_tile_split));
     } else if (wmedian_tile_gen_supported(mp.win) && ctx->tune.wmedian_tile != 0) {
-        // 17x17 .. 37x37: the same scheme with the window a run-time parameter (k_wmedian_tile_gen.hip), 6 or 12 KB of list per
+        // 3x3 .. 13x13, 17x17 .. 37x37: the same scheme with the window a run-time parameter (k_wmedian_tile_gen.hip), 1.5 .. 12 KB of list per
         // block and slice
         const size_t per_slice = wmedian_tile_list_slots(H, W, 1) / 512 * (size_t)wmedian_tile_gen_slots(mp.win);
         int chunk = (int)std::min<size_t>((size_t)n, std::max<size_t>(8, (((size_t)2 << 30) / 6 / per_slice) / 8 * 8));

@@ -1,9 +1,9 @@
-// Weighted-median aggregation (computeAdaptiveWeight_WeightedMedian, M.cpp:3228-3308), tile form for the windows ABOVE 15x15
-// (17x17 ... 37x37; the header's default for this method is 35, M.h:179-182).  Same idea as k_wmedian_tile.hip -- the costs of
+// Weighted-median aggregation (computeAdaptiveWeight_WeightedMedian, M.cpp:3228-3308), tile form for every window but 15x15
+// (3x3 ... 13x13 and 17x17 ... 37x37; the header's default for this method is 35, M.h:179-182).  Same idea as k_wmedian_tile.hip -- the costs of
 // slice d are one plane shared by all pixels, so the neighbourhood of an 8x8 pixel block is sorted ONCE per slice and every
 // pixel walks the sorted list with its own weights -- with the window size a run-time parameter:
-//   region  (8 + win - 1)^2 samples of the REFLECT-indexed cost plane: 1024 slots (16 per lane) up to 25x25, 2048 (32 per
-//           lane) up to 37x37; larger windows keep the per-pixel sort (k_wmedian_big), their region does not fit 2048 slots;
+//   region  (8 + win - 1)^2 samples of the REFLECT-indexed cost plane: 256 slots (4 per lane) up to 9x9, 512 up to 13x13, 1024
+//           (16 per lane) up to 25x25, 2048 (32 per lane) up to 37x37; larger windows keep the per-pixel sort (k_wmedian_big), their region does not fit 2048 slots;
 //   key     (cost bits - bits(4096.0f)) * 4096 + (row * 64 + column) as an exact f64 integer: a compare-exchange is a
 //           v_min_f64 / v_max_f64 pair and the order is the multimap's (cost, row-major insertion order, M.cpp:3276-3283);
 //   walk    an entry's position relative to the pixel indexes a (win x 64)-entry table that yields the byte offset of its
@@ -77,10 +77,14 @@ __global__ __launch_bounds__(256) void k_wmg_sort(const float* __restrict__ cost
     }
 #pragma unroll
     for (int r = 0; r < KPL; r += 4) *reinterpret_cast<uint4*>(listC + base + r) = make_uint4(oc[r], oc[r + 1], oc[r + 2], oc[r + 3]);
+    if constexpr (KPL == 4) {
+        *reinterpret_cast<uint2*>(listP + base) = make_uint2(op[0] | (op[1] << 16), op[2] | (op[3] << 16));
+    } else {
 #pragma unroll
-    for (int r = 0; r < KPL; r += 8)
-        *reinterpret_cast<uint4*>(listP + base + r) =
-            make_uint4(op[r] | (op[r + 1] << 16), op[r + 2] | (op[r + 3] << 16), op[r + 4] | (op[r + 5] << 16), op[r + 6] | (op[r + 7] << 16));
+        for (int r = 0; r < KPL; r += 8)
+            *reinterpret_cast<uint4*>(listP + base + r) =
+                make_uint4(op[r] | (op[r + 1] << 16), op[r + 2] | (op[r + 3] << 16), op[r + 4] | (op[r + 5] << 16), op[r + 6] | (op[r + 7] << 16));
+    }
 }
 
 // ---- 2. every pixel of a part walks the sorted region ----------------------------------------------------------------------
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)
                                                       int d_count, float* __restrict__ out /* [numD][H][W] */)
 {
     constexpr int SLOTS = 64 * KPL;
-    constexpr int NCI = KPL == 16 ? 10 : 22;  // cells of a window in wavefront passes: 25^2 = 625 <= 640, 37^2 = 1369 <= 1408
+    constexpr int NCI = KPL == 32 ? 22 : (KPL == 16 ? 10 : (KPL == 8 ? 3 : 2));  // cells of a window in wavefront passes: 37^2 = 1369 <= 1408, 25^2 = 625 <= 640, 13^2 = 169 <= 192, 9^2 = 81 <= 128
     extern __shared__ __align__(16) unsigned char smem[];
     const int NC = win * win, hw = win / 2, wls = (NC + 1 + 3) & ~3, NT = win * 64 + 1, npart = BW * rpp;
     float* sWL = reinterpret_cast<float*>(smem);
@@ -169,8 +173,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)
         const size_t lbase0 = ((size_t)blk * d_count + dd) * SLOTS;
         const size_t lbase = lbase0 + (size_t)lane * KPL;
         int epos[KPL];  // twice the position: the byte offset into the u16 table needs no shift per pixel
+        if constexpr (KPL == 4) {
+            const uint2 pp = *reinterpret_cast<const uint2*>(listP + lbase);
+            epos[0] = 2 * (int)(pp.x & 0xffffu); epos[1] = 2 * (int)(pp.x >> 16);
+            epos[2] = 2 * (int)(pp.y & 0xffffu); epos[3] = 2 * (int)(pp.y >> 16);
+        } else
 #pragma unroll
-        for (int r = 0; r < KPL; r += 8) {
+        for (int r = 0; r + 7 < KPL; r += 8) {
             const uint4 pp = *reinterpret_cast<const uint4*>(listP + lbase + r);
             epos[r] = 2 * (int)(pp.x & 0xffffu); epos[r + 1] = 2 * (int)(pp.x >> 16);
             epos[r + 2] = 2 * (int)(pp.y & 0xffffu); epos[r + 3] = 2 * (int)(pp.y >> 16);
@@ -284,11 +293,15 @@ int launch_t(hipStream_t s, const float* cost, const float* wLd, const float* wR
 
 }  // namespace
 
-// Windows the general tile form serves (odd; 15x15 has its own kernels, larger regions do not fit 2048 slots).
-bool wmedian_tile_gen_supported(int win) { return (win & 1) && win >= 17 && win <= 37; }
+// Windows the general tile form serves (odd; 15x15 has its own kernels, larger regions do not fit 2048 slots, 1x1 has nothing to sort).
+bool wmedian_tile_gen_supported(int win) { return (win & 1) && win >= 3 && win <= 37 && win != 15; }
 
-// Sorted-list slots per (block, slice) of the general tile form.
-int wmedian_tile_gen_slots(int win) { return (BW + win - 1) * (BH + win - 1) <= 1024 ? 1024 : 2048; }
+// Sorted-list slots per (block, slice) of the general tile form: 256 up to 9x9, 512 up to 13x13, 1024 up to 25x25, else 2048.
+int wmedian_tile_gen_slots(int win)
+{
+    const int nreg = (BW + win - 1) * (BH + win - 1);
+    return nreg <= 256 ? 256 : (nreg <= 512 ? 512 : (nreg <= 1024 ? 1024 : 2048));
+}
 
 // Slices [d_begin, d_begin + d_count) of the weighted median at window `win`; listC: u32[blocks * d_count * slots], listP: u16[same].
 // rows_per_part (0 = default): rows of the 8x8 block a workgroup keeps in LDS: 1 | 2 | 4 | 8.
@@ -296,10 +309,12 @@ int launch_wmedian_tile_gen(hipStream_t s, const float* cost, const float* wLd, 
                             int max_off, int d_begin, int d_count, uint32_t* listC, uint16_t* listP, float* out, int rows_per_part)
 {
     if (!wmedian_tile_gen_supported(win) || d_count <= 0 || d_begin < 0 || d_begin + d_count > numD) return ASW_ERR_BAD_ARGUMENT;
-    const bool small = wmedian_tile_gen_slots(win) == 1024;
+    const int slots = wmedian_tile_gen_slots(win);
     int rpp = rows_per_part;
-    if (rpp != 1 && rpp != 2 && rpp != 4 && rpp != 8) rpp = small ? 2 : 1;
-    if (small) return launch_t<16, 8, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
+    if (rpp != 1 && rpp != 2 && rpp != 4 && rpp != 8) rpp = slots <= 512 ? 4 : (slots == 1024 ? 2 : 1);
+    if (slots == 256) return launch_t<4, 8, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
+    if (slots == 512) return launch_t<8, 8, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
+    if (slots == 1024) return launch_t<16, 8, 4>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);
     // 2048 slots: 180 registers, two workgroups of four wavefronts per CU (2 x 63 KB of LDS at 35x35).  Two workgroups of SIX
     // wavefronts at a register target of 168 (three per SIMD, 10 registers spilled): 201 against 158 ms at 35x35, 152 / 132 at 27x27.
     return launch_t<32, 4, 2>(s, cost, wLd, wRb, H, W, win, numD, max_off, d_begin, d_count, listC, listP, out, rpp);

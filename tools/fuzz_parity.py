@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
                     "both directions, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
-    ap.add_argument("--wmbig", type=float, default=0.0, help="share of the cases forced to the weighted median at 17x17 .. 41x41 (general tile form, k_wmedian_tile_gen.hip; per-pixel sort above 37)")
+    ap.add_argument("--wmbig", type=float, default=0.0, help="share of the cases forced to the weighted median at 3x3 .. 13x13 and 17x17 .. 41x41 (general tile form, k_wmedian_tile_gen.hip; per-pixel sort above 37)")
     ap.add_argument("--wm15", type=float, default=0.0, help="share of the cases forced to the 15x15 weighted median (the tile form, k_wmedian_tile.hip)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -90,7 +90,7 @@ def main():
             method, win, dt = "wmedian", 15, 0
             numD = int(rng.integers(1, 40))
         if rng.random() < args.wmbig:
-            method, win, dt = "wmedian", int(rng.choice([17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37, 39, 41])), 0
+            method, win, dt = "wmedian", int(rng.choice([3, 5, 7, 9, 11, 13, 17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37, 39, 41])), 0
             H, W, numD = int(rng.integers(1, 36)), int(rng.integers(1, 90)), int(rng.integers(1, 20))
             minD = int(rng.choice([0, 0, 1, 4]))
             seed = int(rng.integers(0, 1 << 30))
