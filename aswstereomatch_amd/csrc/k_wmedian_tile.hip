@@ -168,14 +168,19 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
 {
     constexpr int NPART = NPIX / NSPLIT;
     __shared__ float sWL[NPART * WLS];        // 57 856 B / NSPLIT: (wL .mul wd) of this part's pixels
-    // 22 592 B: the weights of the pixel a wavefront is working on at its d, laid out by position RELATIVE to the window's first
+    // 25 600 B (COMPACT): the weights of the pixel a wavefront is working on at its d, laid out by position RELATIVE to the window's first
     // cell (t = dy * 47 + dx + 7): a list entry gathers its weight with ONE LDS read at (its position - the pixel's), no table
     // in between.  Every slot that is not a window cell holds -0.0f: adding it changes no sum (x + -0.0 = x), and its bit
     // pattern says "not a member" (a weight product is never -0.0: both factors are >= +0).
-    __shared__ float sWR[PICK_WAVES][LAY];
+    // COMPACT: the list holds region rows ly0 .. ly0 + 15 only and the part's pixels sit in rows ly0 / ly0 + 1, so an entry's row
+    // relative to the window is -1 .. 15: with one guard row in front (and the clamp slot behind) EVERY address an entry can form
+    // lies inside the layout -- no clamp, one v_add per gather instead of add / min / add.
+    constexpr int LAYW = COMPACT ? (WIN + 2) * PS + 1 : LAY;
+    constexpr int ROW0 = COMPACT ? PS : 0;   // slot of the window's first row
+    __shared__ float sWR[PICK_WAVES][LAYW];
     constexpr int KE = COMPACT ? 6 : KPL;     // list entries per lane in the walk
     static_assert(!COMPACT || NSPLIT == 4, "the compacted list holds the 16 region rows of a two-row part");
-    static_assert(64 * 6 <= LAY, "the compaction buffer (original slot << 16 | position) borrows the wavefront's layout");
+    static_assert(64 * 6 <= LAY && LAY <= (WIN + 2) * PS, "the compaction buffer (original slot << 16 | position) borrows the wavefront's layout");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // one-dimensional grid of (block, part) pairs; every XCD takes a contiguous run of them, so the parts of a block -- which
     // read the same sorted lists -- run on one XCD at about the same time and the lists come from HBM once, not once per part
@@ -195,13 +200,13 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
         sWL[i] = (c < NC && x < W && y < H) ? wLd[((size_t)y * W + x) * NC + c] : 0.0f;
     }
     float* wrp = sWR[wv];
-    for (int i = lane; i < LAY; i += 64) wrp[i] = -0.0f;
+    for (int i = lane; i < LAYW; i += 64) wrp[i] = -0.0f;
     // byte offset of window cell c = lane + 64 k in the layout
     int coff[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int c = min(lane + 64 * k, NC - 1), cy = c / WIN;
-        coff[k] = 4 * (cy * PS + (c - cy * WIN) + HW);
+        coff[k] = 4 * (ROW0 + cy * PS + (c - cy * WIN) + HW);
     }
     __syncthreads();
 
@@ -225,12 +230,13 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             int cnt = 0;
 #pragma unroll
             for (int r = 0; r < KPL; r++) {
-                keep[r] = (uint32_t)(pos[r] - ly0 * PS) < 16u * PS;  // rows ly0 .. ly0 + 15; padding entries (position 1023) never stay
+                keep[r] = (uint32_t)(pos[r] - ly0 * PS) < 16u * PS && pos[r] != (int)POS_PAD;  // rows ly0 .. ly0 + 15, no padding entries
                 cnt += keep[r] ? 1 : 0;
             }
             uint32_t* cb = reinterpret_cast<uint32_t*>(wrp);  // the layout is rebuilt below
 #pragma unroll
-            for (int i = 0; i < KE; i++) cb[lane + 64 * i] = POS_PAD;  // slots behind the last kept entry: never a member
+            // slots behind the last kept entry: a position of the kept rows whose column (40) is outside every window
+            for (int i = 0; i < KE; i++) cb[lane + 64 * i] = (uint32_t)(ly0 * PS + 40);
             int o = wave_inclusive_scan(cnt) - cnt;
 #pragma unroll
             for (int r = 0; r < KPL; r++) {
@@ -287,12 +293,18 @@ __global__ __launch_bounds__(64 * PICK_WAVES) void k_wm_pick(const float* __rest
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             const int base4 = 4 * ((p >> 3) * PS + (p & 7) - HW);
+            const char* wqe = wq + 4 * ROW0 - base4;  // COMPACT: wave-uniform, so a gather address is one addition
             double run = 0.0, pre[KE];
             uint32_t mb = 0;  // member flags of this lane's entries, entry r at bit KE - 1 - r
 #pragma unroll
             for (int r = 0; r < KE; r++) {
-                const uint32_t t4 = min((uint32_t)(epos[r] - base4), (uint32_t)(4 * (LAY - 1)));  // rows above the window wrap to huge values
-                const float w = *reinterpret_cast<const float*>(wq + t4);  // the cell's weight; -0.0 outside the window
+                float w;  // the cell's weight; -0.0 outside the window
+                if constexpr (COMPACT) {
+                    w = *reinterpret_cast<const float*>(wqe + epos[r]);
+                } else {
+                    const uint32_t t4 = min((uint32_t)(epos[r] - base4), (uint32_t)(4 * (LAY - 1)));  // rows above the window wrap to huge values
+                    w = *reinterpret_cast<const float*>(wq + t4);
+                }
                 run = r == 0 ? (double)w : run + (double)w;
                 pre[r] = run;
                 mb = (mb << 1) | (__float_as_uint(w) != 0x80000000u ? 1u : 0u);
