@@ -82,6 +82,7 @@ void AswTuning::read_environment()
     ring_ab = num("ASW_RING_AB", ring_ab);
     ring_q = num("ASW_RING_Q", ring_q);
     q_wg_strips = num("ASW_Q_WG_STRIPS", q_wg_strips);
+    guided_fused = num("ASW_GUIDED_FUSED", guided_fused);
 }
 
 extern "C" int asw_create(int device_id, asw_ctx** out)

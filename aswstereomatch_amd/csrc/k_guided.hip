@@ -1121,6 +1121,313 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active, o);
 }
 
+// ---- fused a/b -> q pass: slice-independent 3-channel guide, 15x15 (GuidedF_2), finite costs -------------------------------------
+// One walk does both box stages: the a/b values of a row go straight from the first stage's horizontal pass into the second
+// stage's vertical running sums; the last 15 a/b rows of the lane's two columns live in a second register ring (128 registers).
+// Nothing of the 4.4 GB a/b volume touches memory: a step loads the cost and the guide word of the entering row (the leaving
+// row comes from the first ring), the guide statistics of the a/b row and the guide pixel of the q row -- all but the cost hit
+// in L2 -- and stores two q values.  Price: 2 x 14 halo columns per 128-column strip (100 outputs) and 28 warm-up rows per band,
+// and ~300 registers: ONE wavefront per SIMD, so every load is issued PF steps ahead and all four planes' LDS reads of a
+// horizontal pass are in flight together.
+// NOT the default: 4.18 ms against 3.49 ms for the two passes (1080p, D = 128) although it moves 4.3 GB instead of 13.6 -- with one
+// wavefront per SIMD nothing overlaps the two LDS exchanges and the f64 chains of a step (ASW_GUIDED_FUSED=1 selects it; results
+// are bit-identical to the two-pass path on every frame tried, borders included).
+// Borders: a/b at a virtual row / column -k is a/b(k) (BORDER_REFLECT_101 of the second boxFilter); the first stage evaluated at
+// the virtual position sees the mirrored window of position k -- the same multiset of cost samples, summed in f64 in another
+// order -- and takes the statistics of position k, so no border case exists in the walk.
+struct FusedArgs {
+    GuideAccT<false> g;
+    const float* P;          // raw cost volume [n][H][W]
+    const float2* pscales;   // per-slice normalize() parameters
+    StatsPlanes sp;
+    float* q;                // [n][H][W]
+    int H, W, n, band, nxw, nby;
+};
+
+template <int PF, int WPE, bool R1, int HGRP>
+__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_guided_fused3(FusedArgs a)
+{
+    constexpr int K = 15, HL = 7, SW = 128, XO1 = SW - (K - 1), XO2 = SW - 2 * (K - 1), NPL = 4, HP = (K - 1) / 2;
+    constexpr int NPH = PF + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* hs1 = reinterpret_cast<double*>(smem) + (size_t)wv * 2 * NPL * (SW + 2);  // [NPL][SW+2], first stage
+    double* hs2 = hs1 + NPL * (SW + 2);                                                // second stage
+    const int H = a.H, W = a.W;
+    // workgroup -> (region = strip x band, four consecutive slices): every XCD takes a contiguous run of regions and runs
+    // through all slices of a region before the next one (guide words and statistics of a region then hit in its L2)
+    const int nzg = (a.n + 3) >> 2;
+    const int wj = blockIdx.x >> 3;
+    const int nreg = a.nxw * a.nby, rpx = (nreg + 7) >> 3;
+    const int reg = (blockIdx.x & 7) * rpx + wj / nzg;
+    if (wj / nzg >= rpx || reg >= nreg) return;
+    const int xw = reg % a.nxw, by = reg / a.nxw;
+    const int kz = (wj % nzg) * 4 + wv;
+    if (kz >= a.n) return;  // whole wavefront (no workgroup barrier anywhere below)
+    const int xo0 = xw * XO2, c0 = 2 * lane;
+    const int y0 = by * a.band, y1 = min(H, y0 + a.band);
+    const size_t plane = (size_t)H * W;
+    const float* pc[2];
+    const uint32_t* gc[2];
+    const double* rs[2];
+    const float* ms[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int xi = reflect101_idx(xo0 - 2 * HL + c0 + c, W);  // input column of strip column c0 + c
+        const int xs = reflect101_idx(xo0 - HL + c0 + c, W);      // a/b column of this lane's first-stage output
+        pc[c] = a.P + (size_t)kz * plane + xi;
+        gc[c] = a.g.A + xi;
+        rs[c] = a.sp.R + xs;
+        ms[c] = a.sp.M + xs;
+    }
+    const int xq = xo0 + c0;
+    const bool ab_lane = c0 < XO1, q_lane = c0 < XO2 && xq < W, q_second = c0 + 1 < XO2 && xq + 1 < W;
+    const uint32_t* gq = a.g.A + min(xq, W - 1);
+    float* qo = a.q + (size_t)kz * plane + min(xq, W - 1);
+    const float2 psc = a.pscales[kz], gsc = a.g.scales[0];
+    const double scale = 1.0 / ((double)K * (double)K);
+
+    double vs1[2][NPL], vs2[2][NPL];
+    // R1: the first stage's leaving row {cost, guide word} from a register ring too; else fetched again (an L2 hit: the same
+    // wavefront read it 15 steps ago) -- 64 registers less
+    v16u ring1[R1 ? 2 : 1][R1 ? 2 : 1], ring2[2][NPL];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int p = 0; p < NPL; p++) { vs1[c][p] = 0.0; vs2[c][p] = 0.0; ring2[c][p] = 0; }
+        if constexpr (R1) { ring1[c][0] = 0; ring1[c][1] = 0; }
+    }
+    int slot1 = 0, slot2 = 0;
+    const int steps = (y1 - y0) + 2 * (K - 1);
+
+    // register FIFO of the loads, PF steps deep, the slot a compile-time phase (see k_box_walk)
+    float fP[NPH][2], fPo[NPH][2];
+    uint32_t fG[NPH][2], fGo[NPH][2];
+    auto issue = [&](int s, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
+        const size_t rn = (size_t)reflect101_idx(y0 - 2 * HL + s, H) * W;        // entering input row
+        const size_t ro = (size_t)reflect101_idx(y0 - 2 * HL + s - K, H) * W;    // leaving input row (!R1)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            fP[SL][c] = pc[c][rn];
+            fG[SL][c] = gc[c][rn];
+            if constexpr (!R1) { fPo[SL][c] = pc[c][ro]; fGo[SL][c] = gc[c][ro]; }
+        }
+    };
+    if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
+    if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
+
+    auto guide = [&](uint32_t u, float (&I)[3]) __attribute__((always_inline)) {
+        I[0] = (float)(u & 0xffu) * gsc.x + gsc.y;
+        I[1] = (float)((u >> 8) & 0xffu) * gsc.x + gsc.y;
+        I[2] = (float)((u >> 16) & 0xffu) * gsc.x + gsc.y;
+    };
+    // horizontal 15-wide sums of both columns of every lane: pair sums through the wave-private strip (k_box_walk, PAIRS)
+    auto hpass = [&](double* hs, const double (&vs)[2][NPL], bool reader, float (&m)[2][NPL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NPL; p++) {
+            hs[p * (SW + 2) + c0] = vs[0][p] + vs[1][p];
+            hs[p * (SW + 2) + c0 + 1] = vs[0][p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < NPL; p++) { m[0][p] = 0.0f; m[1][p] = 0.0f; }
+        if (reader) {
+            constexpr int GRP = HGRP;  // planes whose reads are in flight together (18 registers each)
+#pragma unroll
+            for (int p0 = 0; p0 < NPL; p0 += GRP) {
+                double bb[GRP][2 * HP + 2];
+#pragma unroll
+                for (int g = 0; g < GRP; g++) {
+                    const double* b = hs + (p0 + g) * (SW + 2) + c0;
+#pragma unroll
+                    for (int i = 2; i < 2 * HP + 2; i++)
+                        if (!(i & 1) || i == 2 * HP + 1) bb[g][i] = b[i];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // the group's reads in flight before the first addition
+#pragma unroll
+                for (int g = 0; g < GRP; g++) {
+                    const int p = p0 + g;
+                    double t = bb[g][2];
+#pragma unroll
+                    for (int i = 2; i < HP; i++) t = t + bb[g][2 * i];
+                    const double s0 = ((vs[0][p] + vs[1][p]) + t) + bb[g][2 * HP + 1];
+                    const double s1 = (vs[1][p] + t) + bb[g][2 * HP];
+                    m[0][p] = (float)(s0 * scale);
+                    m[1][p] = (float)(s1 * scale);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    auto step = [&](int s, auto ph_c, auto sub1_c, auto out1_c, auto sub2_c, auto out2_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr bool SUB1 = decltype(sub1_c)::value, OUT1 = decltype(out1_c)::value, SUB2 = decltype(sub2_c)::value,
+                       OUT2 = decltype(out2_c)::value;
+        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
+        // the guide statistics of the a/b row and the guide pixels of the q row of THIS step: L2 hits, needed half a step / a step from here
+        double fR[2][3];
+        float fM[2][3];
+        uint2 fQ = make_uint2(0u, 0u);
+        if constexpr (OUT1) {
+            const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + s, H) * W;  // a/b row the first stage emits at step s
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    fR[c][ch] = rs[c][ch * plane + ra];
+                    fM[c][ch] = ms[c][ch * plane + ra];
+                }
+        }
+        if constexpr (OUT2) {
+            const uint32_t* pq = gq + (size_t)(y0 + s - 2 * (K - 1)) * W;
+            fQ = make_uint2(pq[0], pq[1]);
+        }
+        // ---- first stage: vertical running sums of {P, I_c * P} (M.cpp:2780-2795)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if constexpr (SUB1) {
+                float po;
+                float Io[3];
+                if constexpr (R1) {
+                    po = __uint_as_float(ring1[c][0][slot1]) * psc.x + psc.y;
+                    guide(ring1[c][1][slot1], Io);
+                } else {
+                    po = fPo[PH][c] * psc.x + psc.y;
+                    guide(fGo[PH][c], Io);
+                }
+                vs1[c][0] = vs1[c][0] - (double)po;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) vs1[c][1 + ch] = vs1[c][1 + ch] - (double)(Io[ch] * po);
+            }
+            if constexpr (R1) {
+                ring1[c][0][slot1] = __float_as_uint(fP[PH][c]);
+                ring1[c][1][slot1] = fG[PH][c];
+            }
+            const float pn = fP[PH][c] * psc.x + psc.y;
+            float In[3];
+            guide(fG[PH][c], In);
+            vs1[c][0] = vs1[c][0] + (double)pn;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) vs1[c][1 + ch] = vs1[c][1 + ch] + (double)(In[ch] * pn);
+        }
+        slot1 = slot1 + 1 == K ? 0 : slot1 + 1;
+        if constexpr (OUT1) {
+            float m1[2][NPL];
+            hpass(hs1, vs1, ab_lane, m1);
+            // ---- a_c = cov_c / (var_c + eps), b (M.cpp:2796-2847; the division by the stored f64 reciprocal, see ABDstP)
+            float o[2][NPL];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float meanP = m1[c][0];
+                float dot = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float mI = fM[c][ch];
+                    const float mp = mI * meanP;
+                    const float cov = m1[c][1 + ch] - mp;
+                    const float ac = (float)((double)cov * fR[c][ch]);
+                    o[c][ch] = ac;
+                    const float pr = ac * mI;
+                    dot = (ch == 0) ? pr : dot + pr;
+                }
+                o[c][3] = meanP - dot;
+            }
+            // ---- second stage: vertical running sums of {a_0, a_1, a_2, b} (M.cpp:2849-2850)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int p = 0; p < NPL; p++) {
+                    if constexpr (SUB2) vs2[c][p] = vs2[c][p] - (double)__uint_as_float(ring2[c][p][slot2]);
+                    ring2[c][p][slot2] = __float_as_uint(o[c][p]);
+                    vs2[c][p] = vs2[c][p] + (double)o[c][p];
+                }
+            slot2 = slot2 + 1 == K ? 0 : slot2 + 1;
+            if constexpr (OUT2) {
+                float m2[2][NPL];
+                hpass(hs2, vs2, c0 < XO2, m2);
+                // ---- q = sum_c mean(a_c) * I_c + mean(b) (M.cpp:2851-2852)
+                float qv[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    float I[3];
+                    guide(c == 0 ? fQ.x : fQ.y, I);
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float pr = m2[c][ch] * I[ch];
+                        dot = (ch == 0) ? pr : dot + pr;
+                    }
+                    qv[c] = dot + m2[c][3];
+                }
+                if (q_lane) {
+                    float* o2 = qo + (size_t)(y0 + s - 2 * (K - 1)) * W;
+                    if (q_second) {
+                        typedef float v2f __attribute__((ext_vector_type(2)));
+                        const v2f v = {qv[0], qv[1]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(o2));
+                    } else {
+                        o2[0] = qv[0];
+                    }
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0, ph = 0;
+    auto run = [&](int s_end, auto a1, auto b1, auto a2, auto b2) __attribute__((always_inline)) {
+        if constexpr (NPH > 1) { if (ph == 1 && s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2); s++; ph = 2 % NPH; } }
+        if constexpr (NPH > 2) { if (ph == 2 && s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), a1, b1, a2, b2); s++; ph = 0; } }
+        if (ph == 0) {
+            for (; s + NPH <= s_end; s += NPH) {
+                step(s, std::integral_constant<int, 0>(), a1, b1, a2, b2);
+                if constexpr (NPH > 1) step(s + 1, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2);
+                if constexpr (NPH > 2) step(s + 2, std::integral_constant<int, 2 % NPH>(), a1, b1, a2, b2);
+            }
+            if constexpr (NPH > 1) { if (s < s_end) { step(s, std::integral_constant<int, 0>(), a1, b1, a2, b2); s++; ph = 1; } }
+            if constexpr (NPH > 2) { if (s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2); s++; ph = 2; } }
+        }
+    };
+    // first stage: accumulate K-1 rows, first output without a leaving row, then steady; the second stage the same, K-1 steps later
+    run(min(K - 1, steps), F(), F(), F(), F());
+    run(min(K, steps), F(), T(), F(), F());
+    run(min(2 * (K - 1), steps), T(), T(), F(), F());
+    run(min(2 * K - 1, steps), T(), T(), F(), T());
+    run(steps, T(), T(), T(), T());
+}
+
+int launch_guided_fused3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<false>& g, const StatsPlanes& sp, int pf, int band_opt)
+{
+    constexpr int XO2 = 128 - 28;
+    FusedArgs f;
+    f.g = g; f.P = a.P; f.pscales = a.pscales; f.sp = sp; f.q = a.q; f.H = a.H; f.W = a.W; f.n = a.n;
+    f.nxw = (a.W + XO2 - 1) / XO2;
+    const int nzg = (a.n + 3) / 4;
+    // ~10 rounds of the 256 workgroups the chip holds (one per CU); 28 warm-up rows per band
+    int nb = (int)std::max<long long>(1, (2560 + (long long)f.nxw * nzg - 1) / ((long long)f.nxw * nzg));
+    nb = std::min(nb, std::max(1, a.H / 60));
+    f.band = band_opt >= 30 ? band_opt : (a.H + nb - 1) / nb;
+    f.nby = (a.H + f.band - 1) / f.band;
+    const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * nzg;
+    if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
+    const size_t lds = (size_t)4 * 2 * 4 * (128 + 2) * sizeof(double);
+    // Variants measured at 1080p D=128 (profiles/r03/guided_fused/): both rings in registers, depth 1 / 2: 5.70 / 8.53 ms (470 registers:
+    // half of them AGPRs, and a 16-entry ring vector that lives in AGPRs is copied out and back around every indexed access);
+    // first-stage ring dropped, statistics and q-row guide loaded in their own step, LDS reads of two planes in flight: 4.18 ms
+    // (284 registers); all four planes in flight 4.34; depth 2: 4.20; two wavefronts per SIMD (34 / 113 registers spilled to
+    // scratch): 5.28 / 5.46 ms.
+    (void)pf;
+    hipLaunchKernelGGL((k_guided_fused3<1, 1, false, 2>), dim3((unsigned)nwg), dim3(BW), lds, s, f);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
 // the 3-channel guided filter (statistics, a/b, q) on the planar layouts, the two big passes in the forms AswTuning selects
 template <bool SHIFT>
 int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>& g, int nstat)
@@ -1133,6 +1440,10 @@ int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>&
         StatsDstP sd{sp, a.W, (float)a.eps};
         rc = launch_walk<6>(s, ss, sd, a.H, a.W, a.r, nstat);
         if (rc != ASW_OK) return rc;
+    }
+    if constexpr (!SHIFT) {
+        // ASW_GUIDED_FUSED=1: one fused a/b -> q walk, no a/b volume (a third of the HBM traffic, 20 % slower: see k_guided_fused3)
+        if (t.guided_fused > 0 && a.r == 15 && !a.nan_safe && nstat == 1 && a.H >= 16) return launch_guided_fused3(s, a, g, sp, t.guided_fused, t.band_q);
     }
     const ABTiles at = ab_tiles(a.H, a.W, a.r);
     ABDstP dst{sp, nstat > 1 ? 1 : 0, reinterpret_cast<float2*>(a.ab), at, a.W};

@@ -367,3 +367,22 @@ def test_switches_are_read_once_at_context_creation(oracle):
         del os.environ["ASW_BILATERAL_XQ"]
         forced.close()
         plain.close()
+
+
+def test_guided2_fused_walk_equals_two_pass_path(oracle):
+    """ASW_GUIDED_FUSED=1 (k_guided_fused3: one walk does both box stages, no a/b volume; not the default -- slower) against the
+    two-pass path: bit for bit, image borders included (a/b at a virtual row / column is evaluated on the mirrored window), and
+    against the oracle within the volume tolerance."""
+    base = asw.Context(0)
+    fused = asw.Context(0, env={"ASW_GUIDED_FUSED": "1"})
+    try:
+        for (H, W, D, seed) in ((16, 40, 5, 1), (37, 130, 9, 2), (75, 231, 12, 3), (20, 301, 4, 4)):
+            L, R, _ = make_pair(H, W, D, seed=seed)
+            d0, v0 = base.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, 15, 0, D, return_cost_volume=True)
+            d1, v1 = fused.computeAdaptiveWeight_GuidedF_2(L, R, LEFT, 1e-6, 15, 0, D, return_cost_volume=True)
+            assert np.array_equal(d0, d1) and np.allclose(v0, v1, rtol=1e-6, atol=0)
+            rc, dw, vw = oracle.asw_guided2(L, R, 0, 1e-6, 15, 0, D, want_vol=True)
+            assert rc == 0 and np.allclose(v1, vw, rtol=1e-4, atol=1e-6) and np.array_equal(d1, dw)
+    finally:
+        base.close()
+        fused.close()
