@@ -67,7 +67,7 @@ struct AswTuning {
     int wmedian_gen_rows = 0;    // ASW_WMEDIAN_GEN_ROWS: block rows per workgroup of the general tile form (windows 17..37): 1 | 2 | 4 | 8
     int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
     int ring_ab = 1, ring_q = 1; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_guided3), 0 = re-fetch
-    int guided_fused = 0;        // ASW_GUIDED_FUSED: 1 = fused a/b -> q walk of the 3-channel guided filter at 15x15 (k_guided_fused3: no a/b volume, slower)
+    int guided_fused = 0;        // ASW_GUIDED_FUSED: 1 = fused a/b -> q walk of the 3-channel guided filter at 15x15 (k_guided_pair3: no a/b volume, a third of the traffic, ~5 % slower)
     int q_wg_strips = 1;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
     void read_environment();
 };

@@ -1121,20 +1121,18 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
     return launch_walk_t<NP, 2, ND, 4, NANSAFE>(s, src, dst, H, W, k, n, n_active, o);
 }
 
-// ---- fused a/b -> q pass: slice-independent 3-channel guide, 15x15 (GuidedF_2), finite costs -------------------------------------
+// ---- fused a/b -> q walk: slice-independent 3-channel guide, 15x15 (GuidedF_2), finite costs ------------------------------------
 // One walk does both box stages: the a/b values of a row go straight from the first stage's horizontal pass into the second
-// stage's vertical running sums; the last 15 a/b rows of the lane's two columns live in a second register ring (128 registers).
-// Nothing of the 4.4 GB a/b volume touches memory: a step loads the cost and the guide word of the entering row (the leaving
-// row comes from the first ring), the guide statistics of the a/b row and the guide pixel of the q row -- all but the cost hit
-// in L2 -- and stores two q values.  Price: 2 x 14 halo columns per 128-column strip (100 outputs) and 28 warm-up rows per band,
-// and ~300 registers: ONE wavefront per SIMD, so every load is issued PF steps ahead and all four planes' LDS reads of a
-// horizontal pass are in flight together.
-// NOT the default: 4.18 ms against 3.49 ms for the two passes (1080p, D = 128) although it moves 4.3 GB instead of 13.6 -- with one
-// wavefront per SIMD nothing overlaps the two LDS exchanges and the f64 chains of a step (ASW_GUIDED_FUSED=1 selects it; results
-// are bit-identical to the two-pass path on every frame tried, borders included).
+// stage's vertical running sums, so nothing of the 4.4 GB a/b volume touches memory: a step loads the cost and the guide word of
+// the entering row, the guide statistics of the a/b row and the guide pixels of the q row -- all but the cost hit in L2 -- and
+// stores two q values.  HBM traffic per 1080p D=128 frame: 4.3 GB instead of 13.6 GB.  Price: 2 x 14 halo columns per 128-column
+// strip (100 outputs) and 28 warm-up rows per band.
 // Borders: a/b at a virtual row / column -k is a/b(k) (BORDER_REFLECT_101 of the second boxFilter); the first stage evaluated at
 // the virtual position sees the mirrored window of position k -- the same multiset of cost samples, summed in f64 in another
 // order -- and takes the statistics of position k, so no border case exists in the walk.
+// NOT the default (ASW_GUIDED_FUSED=1 selects it): 3.66-3.83 ms against 3.42-3.60 ms for the two passes on the same boxes.  A first
+// form with both stages in ONE wavefront (both rings: 284-470 registers, one wavefront per SIMD) took 4.18-5.70 ms; the form
+// below splits the stages over a PAIR of wavefronts.  Results are bit-identical to the two-pass path.
 struct FusedArgs {
     GuideAccT<false> g;
     const float* P;          // raw cost volume [n][H][W]
@@ -1144,86 +1142,102 @@ struct FusedArgs {
     int H, W, n, band, nxw, nby;
 };
 
-template <int PF, int WPE, bool R1, int HGRP>
-__global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_guided_fused3(FusedArgs a)
+// Producer / consumer pair: wavefront A runs the first stage of a strip (cost ring, column sums, horizontal pass, a/b arithmetic) and hands every a/b
+// row through a double-buffered LDS slot to wavefront B, which runs the second stage (a/b ring, column sums, horizontal pass, q):
+// each holds one ring -- 236 registers, TWO wavefronts per SIMD -- and the two stages of a strip run concurrently, one row
+// apart, with one workgroup barrier per row.  A workgroup = NPAIR pairs (slices of one strip and band); one pair per workgroup
+// measured 3.71 against 3.84 ms for two (the barrier then couples only the two wavefronts that exchange data).
+// Counters (profiles/r03/guided_fused/): VALU busy 55 % of a SIMD's cycles; a wavefront waits 16 % of its cycles in s_waitcnt
+// (average VMEM latency 840 cycles, LDS 118) and 22 % at the barrier; the kernel issues 1.04e9 VALU instructions against 8.3e8
+// of the two passes (100 instead of 114 outputs per strip, the exchange).  Variants that lost: the statistics loaded a step
+// ahead (30 registers spilled: 4.51 ms), LDS reads of all four planes in flight (20 spilled: 5.21), b computed by the
+// consumer (4.04), s_setprio for the producer (3.81).
+template <int PF, int HGRP, bool STATF, int NPAIR>
+__global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_guided_pair3(FusedArgs a)
 {
     constexpr int K = 15, HL = 7, SW = 128, XO1 = SW - (K - 1), XO2 = SW - 2 * (K - 1), NPL = 4, HP = (K - 1) / 2;
     constexpr int NPH = PF + 1;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* hs1 = reinterpret_cast<double*>(smem) + (size_t)wv * 2 * NPL * (SW + 2);  // [NPL][SW+2], first stage
-    double* hs2 = hs1 + NPL * (SW + 2);                                                // second stage
+    const int role = wv & 1, pr = wv >> 1;  // role 0: first stage (A), 1: second stage (B); pair 0 / 1
+    // per pair: double hsA[NPL][SW+2] | double hsB[NPL][SW+2] | float xch[2][NPL][SW]
+    constexpr int PAIR_BYTES = 2 * NPL * (SW + 2) * 8 + 2 * NPL * SW * 4;
+    unsigned char* pbase = smem + (size_t)pr * PAIR_BYTES;
+    double* hs = reinterpret_cast<double*>(pbase) + (role ? NPL * (SW + 2) : 0);
+    float* xch = reinterpret_cast<float*>(pbase + 2 * NPL * (SW + 2) * 8);
     const int H = a.H, W = a.W;
-    // workgroup -> (region = strip x band, four consecutive slices): every XCD takes a contiguous run of regions and runs
-    // through all slices of a region before the next one (guide words and statistics of a region then hit in its L2)
-    const int nzg = (a.n + 3) >> 2;
+    const int nzg = (a.n + NPAIR - 1) / NPAIR;
     const int wj = blockIdx.x >> 3;
     const int nreg = a.nxw * a.nby, rpx = (nreg + 7) >> 3;
     const int reg = (blockIdx.x & 7) * rpx + wj / nzg;
-    if (wj / nzg >= rpx || reg >= nreg) return;
+    if (wj / nzg >= rpx || reg >= nreg) return;  // whole workgroup
     const int xw = reg % a.nxw, by = reg / a.nxw;
-    const int kz = (wj % nzg) * 4 + wv;
-    if (kz >= a.n) return;  // whole wavefront (no workgroup barrier anywhere below)
+    const int kz = (wj % nzg) * NPAIR + pr;
+    const bool live = kz < a.n;                   // a pair without a slice still keeps the workgroup's barriers
+    const int kzc = min(kz, a.n - 1);
     const int xo0 = xw * XO2, c0 = 2 * lane;
     const int y0 = by * a.band, y1 = min(H, y0 + a.band);
     const size_t plane = (size_t)H * W;
-    const float* pc[2];
-    const uint32_t* gc[2];
-    const double* rs[2];
-    const float* ms[2];
+    // wave-uniform bases + 32-bit per-lane column offsets: the loads take the SGPR-base form, no 64-bit address arithmetic per lane
+    const float* Pz = a.P + (size_t)kzc * plane;
+    const uint32_t* GA = a.g.A;
+    const double* RS = a.sp.R;
+    const float* MS = a.sp.M;
+    uint32_t xi[2], xs_[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        const int xi = reflect101_idx(xo0 - 2 * HL + c0 + c, W);  // input column of strip column c0 + c
-        const int xs = reflect101_idx(xo0 - HL + c0 + c, W);      // a/b column of this lane's first-stage output
-        pc[c] = a.P + (size_t)kz * plane + xi;
-        gc[c] = a.g.A + xi;
-        rs[c] = a.sp.R + xs;
-        ms[c] = a.sp.M + xs;
+        xi[c] = (uint32_t)reflect101_idx(xo0 - 2 * HL + c0 + c, W);
+        xs_[c] = (uint32_t)reflect101_idx(xo0 - HL + c0 + c, W);
     }
     const int xq = xo0 + c0;
-    const bool ab_lane = c0 < XO1, q_lane = c0 < XO2 && xq < W, q_second = c0 + 1 < XO2 && xq + 1 < W;
-    const uint32_t* gq = a.g.A + min(xq, W - 1);
-    float* qo = a.q + (size_t)kz * plane + min(xq, W - 1);
-    const float2 psc = a.pscales[kz], gsc = a.g.scales[0];
+    const bool ab_lane = c0 < XO1, q_lane = live && c0 < XO2 && xq < W, q_second = c0 + 1 < XO2 && xq + 1 < W;
+    const uint32_t xqc = (uint32_t)min(xq, W - 1);
+    float* Qz = a.q + (size_t)kzc * plane;
+    const float2 psc = a.pscales[kzc], gsc = a.g.scales[0];
     const double scale = 1.0 / ((double)K * (double)K);
 
-    double vs1[2][NPL], vs2[2][NPL];
-    // R1: the first stage's leaving row {cost, guide word} from a register ring too; else fetched again (an L2 hit: the same
-    // wavefront read it 15 steps ago) -- 64 registers less
-    v16u ring1[R1 ? 2 : 1][R1 ? 2 : 1], ring2[2][NPL];
+    double vs[2][NPL];          // A: {P, I_c P} column sums; B: {a_c, b} column sums
+    v16u ring[2][NPL];          // A uses [c][0..1] = {cost, guide word}; B all four planes
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < 2; c++)
 #pragma unroll
-        for (int p = 0; p < NPL; p++) { vs1[c][p] = 0.0; vs2[c][p] = 0.0; ring2[c][p] = 0; }
-        if constexpr (R1) { ring1[c][0] = 0; ring1[c][1] = 0; }
-    }
-    int slot1 = 0, slot2 = 0;
-    const int steps = (y1 - y0) + 2 * (K - 1);
+        for (int p = 0; p < NPL; p++) { vs[c][p] = 0.0; ring[c][p] = 0; }
+    int slot = 0;
+    const int iters = (y1 - y0) + 2 * (K - 1);  // A steps 0 .. iters-1; B handles a/b row t = it - (K-1) in iteration it
 
-    // register FIFO of the loads, PF steps deep, the slot a compile-time phase (see k_box_walk)
-    float fP[NPH][2], fPo[NPH][2];
-    uint32_t fG[NPH][2], fGo[NPH][2];
+    float fP[NPH][2];
+    uint32_t fG[NPH][2];
+    double fRf[STATF ? NPH : 1][2][3];
+    float fMf[STATF ? NPH : 1][2][3];
     auto issue = [&](int s, auto slot_c) __attribute__((always_inline)) {
         constexpr int SL = decltype(slot_c)::value;
-        const size_t rn = (size_t)reflect101_idx(y0 - 2 * HL + s, H) * W;        // entering input row
-        const size_t ro = (size_t)reflect101_idx(y0 - 2 * HL + s - K, H) * W;    // leaving input row (!R1)
+        const size_t rn = (size_t)reflect101_idx(y0 - 2 * HL + s, H) * W;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            fP[SL][c] = pc[c][rn];
-            fG[SL][c] = gc[c][rn];
-            if constexpr (!R1) { fPo[SL][c] = pc[c][ro]; fGo[SL][c] = gc[c][ro]; }
+            fP[SL][c] = (Pz + rn)[xi[c]];
+            fG[SL][c] = (GA + rn)[xi[c]];
+        }
+        if constexpr (STATF) {  // the statistics of the a/b row of step s, a step ahead too
+            const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + s, H) * W;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    fRf[SL][c][ch] = (RS + (ch * plane + ra))[xs_[c]];
+                    fMf[SL][c][ch] = (MS + (ch * plane + ra))[xs_[c]];
+                }
         }
     };
-    if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
-    if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
-
+    if (role == 0) {
+        if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
+        if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
+    }
     auto guide = [&](uint32_t u, float (&I)[3]) __attribute__((always_inline)) {
         I[0] = (float)(u & 0xffu) * gsc.x + gsc.y;
         I[1] = (float)((u >> 8) & 0xffu) * gsc.x + gsc.y;
         I[2] = (float)((u >> 16) & 0xffu) * gsc.x + gsc.y;
     };
-    // horizontal 15-wide sums of both columns of every lane: pair sums through the wave-private strip (k_box_walk, PAIRS)
-    auto hpass = [&](double* hs, const double (&vs)[2][NPL], bool reader, float (&m)[2][NPL]) __attribute__((always_inline)) {
+    auto hpass = [&](bool reader, float (&m)[2][NPL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < NPL; p++) {
             hs[p * (SW + 2) + c0] = vs[0][p] + vs[1][p];
@@ -1235,7 +1249,7 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
         for (int p = 0; p < NPL; p++) { m[0][p] = 0.0f; m[1][p] = 0.0f; }
         if (reader) {
-            constexpr int GRP = HGRP;  // planes whose reads are in flight together (18 registers each)
+            constexpr int GRP = HGRP;
 #pragma unroll
             for (int p0 = 0; p0 < NPL; p0 += GRP) {
                 double bb[GRP][2 * HP + 2];
@@ -1246,7 +1260,7 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     for (int i = 2; i < 2 * HP + 2; i++)
                         if (!(i & 1) || i == 2 * HP + 1) bb[g][i] = b[i];
                 }
-                __builtin_amdgcn_sched_barrier(0);  // the group's reads in flight before the first addition
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < GRP; g++) {
                     const int p = p0 + g;
@@ -1265,114 +1279,130 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    auto step = [&](int s, auto ph_c, auto sub1_c, auto out1_c, auto sub2_c, auto out2_c) __attribute__((always_inline)) {
+    // one iteration: A computes input row `it` (and, from it = K-1 on, hands a/b row it-(K-1) to B through slot it & 1); barrier;
+    // B consumes that row (and, from it = 2(K-1) on, emits q row it - 2(K-1)).  B works on row t while A is already at row t+1.
+    auto step = [&](int it, auto ph_c, auto sub1_c, auto out1_c, auto has2_c, auto sub2_c, auto out2_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
-        constexpr bool SUB1 = decltype(sub1_c)::value, OUT1 = decltype(out1_c)::value, SUB2 = decltype(sub2_c)::value,
-                       OUT2 = decltype(out2_c)::value;
-        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
-        // the guide statistics of the a/b row and the guide pixels of the q row of THIS step: L2 hits, needed half a step / a step from here
-        double fR[2][3];
-        float fM[2][3];
-        uint2 fQ = make_uint2(0u, 0u);
-        if constexpr (OUT1) {
-            const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + s, H) * W;  // a/b row the first stage emits at step s
+        constexpr bool SUB1 = decltype(sub1_c)::value, OUT1 = decltype(out1_c)::value, HAS2 = decltype(has2_c)::value,
+                       SUB2 = decltype(sub2_c)::value, OUT2 = decltype(out2_c)::value;
+        float* xs = xch + (it & 1) * (NPL * SW);
+        if (role == 0) {
+            issue(it + PF, std::integral_constant<int, (PH + PF) % NPH>());
+            double fR[2][3];
+            float fM[2][3];
+            if constexpr (OUT1) {
+                if constexpr (STATF) {
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+                    for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    fR[c][ch] = rs[c][ch * plane + ra];
-                    fM[c][ch] = ms[c][ch * plane + ra];
-                }
-        }
-        if constexpr (OUT2) {
-            const uint32_t* pq = gq + (size_t)(y0 + s - 2 * (K - 1)) * W;
-            fQ = make_uint2(pq[0], pq[1]);
-        }
-        // ---- first stage: vertical running sums of {P, I_c * P} (M.cpp:2780-2795)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            if constexpr (SUB1) {
-                float po;
-                float Io[3];
-                if constexpr (R1) {
-                    po = __uint_as_float(ring1[c][0][slot1]) * psc.x + psc.y;
-                    guide(ring1[c][1][slot1], Io);
+                        for (int ch = 0; ch < 3; ch++) { fR[c][ch] = fRf[PH][c][ch]; fM[c][ch] = fMf[PH][c][ch]; }
                 } else {
-                    po = fPo[PH][c] * psc.x + psc.y;
-                    guide(fGo[PH][c], Io);
+                    const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + it, H) * W;  // a/b row emitted in this iteration
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            fR[c][ch] = (RS + (ch * plane + ra))[xs_[c]];
+                            fM[c][ch] = (MS + (ch * plane + ra))[xs_[c]];
+                        }
                 }
-                vs1[c][0] = vs1[c][0] - (double)po;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) vs1[c][1 + ch] = vs1[c][1 + ch] - (double)(Io[ch] * po);
             }
-            if constexpr (R1) {
-                ring1[c][0][slot1] = __float_as_uint(fP[PH][c]);
-                ring1[c][1][slot1] = fG[PH][c];
-            }
-            const float pn = fP[PH][c] * psc.x + psc.y;
-            float In[3];
-            guide(fG[PH][c], In);
-            vs1[c][0] = vs1[c][0] + (double)pn;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) vs1[c][1 + ch] = vs1[c][1 + ch] + (double)(In[ch] * pn);
-        }
-        slot1 = slot1 + 1 == K ? 0 : slot1 + 1;
-        if constexpr (OUT1) {
-            float m1[2][NPL];
-            hpass(hs1, vs1, ab_lane, m1);
-            // ---- a_c = cov_c / (var_c + eps), b (M.cpp:2796-2847; the division by the stored f64 reciprocal, see ABDstP)
-            float o[2][NPL];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const float meanP = m1[c][0];
-                float dot = 0.0f;
+                if constexpr (SUB1) {
+                    const float po = __uint_as_float(ring[c][0][slot]) * psc.x + psc.y;
+                    float Io[3];
+                    guide(ring[c][1][slot], Io);
+                    vs[c][0] = vs[c][0] - (double)po;
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const float mI = fM[c][ch];
-                    const float mp = mI * meanP;
-                    const float cov = m1[c][1 + ch] - mp;
-                    const float ac = (float)((double)cov * fR[c][ch]);
-                    o[c][ch] = ac;
-                    const float pr = ac * mI;
-                    dot = (ch == 0) ? pr : dot + pr;
+                    for (int ch = 0; ch < 3; ch++) vs[c][1 + ch] = vs[c][1 + ch] - (double)(Io[ch] * po);
                 }
-                o[c][3] = meanP - dot;
+                ring[c][0][slot] = __float_as_uint(fP[PH][c]);
+                ring[c][1][slot] = fG[PH][c];
+                const float pn = fP[PH][c] * psc.x + psc.y;
+                float In[3];
+                guide(fG[PH][c], In);
+                vs[c][0] = vs[c][0] + (double)pn;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) vs[c][1 + ch] = vs[c][1 + ch] + (double)(In[ch] * pn);
             }
-            // ---- second stage: vertical running sums of {a_0, a_1, a_2, b} (M.cpp:2849-2850)
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int p = 0; p < NPL; p++) {
-                    if constexpr (SUB2) vs2[c][p] = vs2[c][p] - (double)__uint_as_float(ring2[c][p][slot2]);
-                    ring2[c][p][slot2] = __float_as_uint(o[c][p]);
-                    vs2[c][p] = vs2[c][p] + (double)o[c][p];
-                }
-            slot2 = slot2 + 1 == K ? 0 : slot2 + 1;
-            if constexpr (OUT2) {
-                float m2[2][NPL];
-                hpass(hs2, vs2, c0 < XO2, m2);
-                // ---- q = sum_c mean(a_c) * I_c + mean(b) (M.cpp:2851-2852)
-                float qv[2];
+            slot = slot + 1 == K ? 0 : slot + 1;
+            if constexpr (OUT1) {
+                float m1[2][NPL];
+                hpass(ab_lane, m1);
+                float o[2][NPL];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    float I[3];
-                    guide(c == 0 ? fQ.x : fQ.y, I);
+                    const float meanP = m1[c][0];
                     float dot = 0.0f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        const float pr = m2[c][ch] * I[ch];
-                        dot = (ch == 0) ? pr : dot + pr;
+                        const float mI = fM[c][ch];
+                        const float mp = mI * meanP;
+                        const float cov = m1[c][1 + ch] - mp;
+                        const float ac = (float)((double)cov * fR[c][ch]);
+                        o[c][ch] = ac;
+                        const float pr2 = ac * mI;
+                        dot = (ch == 0) ? pr2 : dot + pr2;
                     }
-                    qv[c] = dot + m2[c][3];
+                    o[c][3] = meanP - dot;
                 }
-                if (q_lane) {
-                    float* o2 = qo + (size_t)(y0 + s - 2 * (K - 1)) * W;
-                    if (q_second) {
-                        typedef float v2f __attribute__((ext_vector_type(2)));
-                        const v2f v = {qv[0], qv[1]};
-                        __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(o2));
-                    } else {
-                        o2[0] = qv[0];
+#pragma unroll
+                for (int p = 0; p < NPL; p++) *reinterpret_cast<float2*>(xs + p * SW + c0) = make_float2(o[0][p], o[1][p]);
+            }
+        }
+        uint2 fQ = make_uint2(0u, 0u);
+        if constexpr (OUT2) {
+            if (role == 1) {  // the q row's guide pixels: in flight across the barrier
+                const uint32_t* pq = GA + (size_t)(y0 + it - 2 * (K - 1)) * W;
+                fQ = make_uint2(pq[xqc], pq[xqc + 1]);
+            }
+        }
+        __syncthreads();
+        if constexpr (HAS2) {
+            if (role == 1) {
+                float o[2][NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; p++) {
+                    const float2 v = *reinterpret_cast<const float2*>(xs + p * SW + c0);
+                    o[0][p] = v.x;
+                    o[1][p] = v.y;
+                }
+
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        if constexpr (SUB2) vs[c][p] = vs[c][p] - (double)__uint_as_float(ring[c][p][slot]);
+                        ring[c][p][slot] = __float_as_uint(o[c][p]);
+                        vs[c][p] = vs[c][p] + (double)o[c][p];
+                    }
+                slot = slot + 1 == K ? 0 : slot + 1;
+                if constexpr (OUT2) {
+                    float m2[2][NPL];
+                    hpass(c0 < XO2, m2);
+                    float qv[2];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        float I[3];
+                        guide(c == 0 ? fQ.x : fQ.y, I);
+                        float dot = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float pr2 = m2[c][ch] * I[ch];
+                            dot = (ch == 0) ? pr2 : dot + pr2;
+                        }
+                        qv[c] = dot + m2[c][3];
+                    }
+                    if (q_lane) {
+                        float* o2 = Qz + (size_t)(y0 + it - 2 * (K - 1)) * W + xqc;
+                        if (q_second) {
+                            typedef float v2f __attribute__((ext_vector_type(2)));
+                            const v2f v = {qv[0], qv[1]};
+                            __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(o2));
+                        } else {
+                            o2[0] = qv[0];
+                        }
                     }
                 }
             }
@@ -1380,50 +1410,42 @@ __global__ __launch_bounds__(BW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     };
     using T = std::true_type;
     using F = std::false_type;
-    int s = 0, ph = 0;
-    auto run = [&](int s_end, auto a1, auto b1, auto a2, auto b2) __attribute__((always_inline)) {
-        if constexpr (NPH > 1) { if (ph == 1 && s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2); s++; ph = 2 % NPH; } }
-        if constexpr (NPH > 2) { if (ph == 2 && s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), a1, b1, a2, b2); s++; ph = 0; } }
+    int it = 0, ph = 0;
+    auto run = [&](int it_end, auto a1, auto b1, auto h2, auto a2, auto b2) __attribute__((always_inline)) {
+        if constexpr (NPH > 1) { if (ph == 1 && it < it_end) { step(it, std::integral_constant<int, 1 % NPH>(), a1, b1, h2, a2, b2); it++; ph = 2 % NPH; } }
+        if constexpr (NPH > 2) { if (ph == 2 && it < it_end) { step(it, std::integral_constant<int, 2 % NPH>(), a1, b1, h2, a2, b2); it++; ph = 0; } }
         if (ph == 0) {
-            for (; s + NPH <= s_end; s += NPH) {
-                step(s, std::integral_constant<int, 0>(), a1, b1, a2, b2);
-                if constexpr (NPH > 1) step(s + 1, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2);
-                if constexpr (NPH > 2) step(s + 2, std::integral_constant<int, 2 % NPH>(), a1, b1, a2, b2);
+            for (; it + NPH <= it_end; it += NPH) {
+                step(it, std::integral_constant<int, 0>(), a1, b1, h2, a2, b2);
+                if constexpr (NPH > 1) step(it + 1, std::integral_constant<int, 1 % NPH>(), a1, b1, h2, a2, b2);
+                if constexpr (NPH > 2) step(it + 2, std::integral_constant<int, 2 % NPH>(), a1, b1, h2, a2, b2);
             }
-            if constexpr (NPH > 1) { if (s < s_end) { step(s, std::integral_constant<int, 0>(), a1, b1, a2, b2); s++; ph = 1; } }
-            if constexpr (NPH > 2) { if (s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), a1, b1, a2, b2); s++; ph = 2; } }
+            if constexpr (NPH > 1) { if (it < it_end) { step(it, std::integral_constant<int, 0>(), a1, b1, h2, a2, b2); it++; ph = 1; } }
+            if constexpr (NPH > 2) { if (it < it_end) { step(it, std::integral_constant<int, 1 % NPH>(), a1, b1, h2, a2, b2); it++; ph = 2; } }
         }
     };
-    // first stage: accumulate K-1 rows, first output without a leaving row, then steady; the second stage the same, K-1 steps later
-    run(min(K - 1, steps), F(), F(), F(), F());
-    run(min(K, steps), F(), T(), F(), F());
-    run(min(2 * (K - 1), steps), T(), T(), F(), F());
-    run(min(2 * K - 1, steps), T(), T(), F(), T());
-    run(steps, T(), T(), T(), T());
+    run(min(K - 1, iters), F(), F(), F(), F(), F());          // A accumulates
+    run(min(K, iters), F(), T(), T(), F(), F());              // first a/b row
+    run(min(2 * (K - 1), iters), T(), T(), T(), F(), F());    // B accumulates
+    run(min(2 * K - 1, iters), T(), T(), T(), F(), T());      // first q row
+    run(iters, T(), T(), T(), T(), T());
 }
 
-int launch_guided_fused3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<false>& g, const StatsPlanes& sp, int pf, int band_opt)
+int launch_guided_fused3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<false>& g, const StatsPlanes& sp, int band_opt)
 {
     constexpr int XO2 = 128 - 28;
     FusedArgs f;
     f.g = g; f.P = a.P; f.pscales = a.pscales; f.sp = sp; f.q = a.q; f.H = a.H; f.W = a.W; f.n = a.n;
     f.nxw = (a.W + XO2 - 1) / XO2;
-    const int nzg = (a.n + 3) / 4;
-    // ~10 rounds of the 256 workgroups the chip holds (one per CU); 28 warm-up rows per band
-    int nb = (int)std::max<long long>(1, (2560 + (long long)f.nxw * nzg - 1) / ((long long)f.nxw * nzg));
+    // ~10 rounds of the 1024 two-wavefront workgroups the chip holds (four per CU); 28 warm-up rows per band
+    int nb = (int)std::max<long long>(1, (10240 + (long long)f.nxw * a.n - 1) / ((long long)f.nxw * a.n));
     nb = std::min(nb, std::max(1, a.H / 60));
     f.band = band_opt >= 30 ? band_opt : (a.H + nb - 1) / nb;
     f.nby = (a.H + f.band - 1) / f.band;
-    const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * nzg;
+    const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * a.n;
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
-    const size_t lds = (size_t)4 * 2 * 4 * (128 + 2) * sizeof(double);
-    // Variants measured at 1080p D=128 (profiles/r03/guided_fused/): both rings in registers, depth 1 / 2: 5.70 / 8.53 ms (470 registers:
-    // half of them AGPRs, and a 16-entry ring vector that lives in AGPRs is copied out and back around every indexed access);
-    // first-stage ring dropped, statistics and q-row guide loaded in their own step, LDS reads of two planes in flight: 4.18 ms
-    // (284 registers); all four planes in flight 4.34; depth 2: 4.20; two wavefronts per SIMD (34 / 113 registers spilled to
-    // scratch): 5.28 / 5.46 ms.
-    (void)pf;
-    hipLaunchKernelGGL((k_guided_fused3<1, 1, false, 2>), dim3((unsigned)nwg), dim3(BW), lds, s, f);
+    const size_t lds = 2 * 4 * (128 + 2) * sizeof(double) + 2 * 4 * 128 * sizeof(float);
+    hipLaunchKernelGGL((k_guided_pair3<1, 2, false, 1>), dim3((unsigned)nwg), dim3(128), lds, s, f);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
@@ -1442,8 +1464,8 @@ int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>&
         if (rc != ASW_OK) return rc;
     }
     if constexpr (!SHIFT) {
-        // ASW_GUIDED_FUSED=1: one fused a/b -> q walk, no a/b volume (a third of the HBM traffic, 20 % slower: see k_guided_fused3)
-        if (t.guided_fused > 0 && a.r == 15 && !a.nan_safe && nstat == 1 && a.H >= 16) return launch_guided_fused3(s, a, g, sp, t.guided_fused, t.band_q);
+        // ASW_GUIDED_FUSED=1: one fused a/b -> q walk, no a/b volume (a third of the HBM traffic, ~5 % slower: see k_guided_pair3)
+        if (t.guided_fused > 0 && a.r == 15 && !a.nan_safe && nstat == 1 && a.H >= 16) return launch_guided_fused3(s, a, g, sp, t.band_q);
     }
     const ABTiles at = ab_tiles(a.H, a.W, a.r);
     ABDstP dst{sp, nstat > 1 ? 1 : 0, reinterpret_cast<float2*>(a.ab), at, a.W};

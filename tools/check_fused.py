@@ -1,5 +1,5 @@
 """Experiment: the fused a/b -> q walk of the 3-channel guided filter (ASW_GUIDED_FUSED) against the two-pass path and the oracle.
-    python tools/check_fused.py [mode ...]      modes: 1 (depth 1), 2 (depth 2), 3 (two wavefronts per SIMD)"""
+    python tools/check_fused.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
