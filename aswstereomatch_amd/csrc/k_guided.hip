@@ -1149,9 +1149,9 @@ struct FusedArgs {
 // measured 3.71 against 3.84 ms for two (the barrier then couples only the two wavefronts that exchange data).
 // Counters (profiles/r03/guided_fused/): VALU busy 55 % of a SIMD's cycles; a wavefront waits 16 % of its cycles in s_waitcnt
 // (average VMEM latency 840 cycles, LDS 118) and 22 % at the barrier; the kernel issues 1.04e9 VALU instructions against 8.3e8
-// of the two passes (100 instead of 114 outputs per strip, the exchange).  Variants that lost: the statistics loaded a step
-// ahead (30 registers spilled: 4.51 ms), LDS reads of all four planes in flight (20 spilled: 5.21), b computed by the
-// consumer (4.04), s_setprio for the producer (3.81).
+// of the two passes (100 instead of 114 outputs per strip, the exchange).  Variants that lost (template parameters kept):
+// the statistics of the next a/b row loaded at the end of the producer's step (STATF: 4.27-4.34 ms), the producer's LDS reads of
+// all four planes in flight (HGRP = 4: 3.70-3.78), b computed by the consumer (4.04), s_setprio for the producer (3.81).
 template <int PF, int HGRP, bool STATF, int NPAIR>
 __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_guided_pair3(FusedArgs a)
 {
@@ -1207,8 +1207,8 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
 
     float fP[NPH][2];
     uint32_t fG[NPH][2];
-    double fRf[STATF ? NPH : 1][2][3];
-    float fMf[STATF ? NPH : 1][2][3];
+    double fRn[2][3];  // STATF: statistics of the NEXT iteration's a/b row, loaded at the end of a producer step (one set of
+    float fMn[2][3];   // registers: they are consumed before the next load is issued, so nothing rotates)
     auto issue = [&](int s, auto slot_c) __attribute__((always_inline)) {
         constexpr int SL = decltype(slot_c)::value;
         const size_t rn = (size_t)reflect101_idx(y0 - 2 * HL + s, H) * W;
@@ -1217,16 +1217,16 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
             fP[SL][c] = (Pz + rn)[xi[c]];
             fG[SL][c] = (GA + rn)[xi[c]];
         }
-        if constexpr (STATF) {  // the statistics of the a/b row of step s, a step ahead too
-            const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + s, H) * W;
+    };
+    auto issue_stats = [&](int s) __attribute__((always_inline)) {
+        const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + s, H) * W;
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    fRf[SL][c][ch] = (RS + (ch * plane + ra))[xs_[c]];
-                    fMf[SL][c][ch] = (MS + (ch * plane + ra))[xs_[c]];
-                }
-        }
+            for (int ch = 0; ch < 3; ch++) {
+                fRn[c][ch] = (RS + (ch * plane + ra))[xs_[c]];
+                fMn[c][ch] = (MS + (ch * plane + ra))[xs_[c]];
+            }
     };
     if (role == 0) {
         if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
         I[1] = (float)((u >> 8) & 0xffu) * gsc.x + gsc.y;
         I[2] = (float)((u >> 16) & 0xffu) * gsc.x + gsc.y;
     };
-    auto hpass = [&](bool reader, float (&m)[2][NPL]) __attribute__((always_inline)) {
+    auto hpass = [&](bool reader, float (&m)[2][NPL], auto grp_c) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < NPL; p++) {
             hs[p * (SW + 2) + c0] = vs[0][p] + vs[1][p];
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int p = 0; p < NPL; p++) { m[0][p] = 0.0f; m[1][p] = 0.0f; }
         if (reader) {
-            constexpr int GRP = HGRP;
+            constexpr int GRP = decltype(grp_c)::value;
 #pragma unroll
             for (int p0 = 0; p0 < NPL; p0 += GRP) {
                 double bb[GRP][2 * HP + 2];
@@ -1291,12 +1291,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
             double fR[2][3];
             float fM[2][3];
             if constexpr (OUT1) {
-                if constexpr (STATF) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) { fR[c][ch] = fRf[PH][c][ch]; fM[c][ch] = fMf[PH][c][ch]; }
-                } else {
+                if constexpr (!STATF) {
                     const size_t ra = (size_t)reflect101_idx(y0 - 3 * HL + it, H) * W;  // a/b row emitted in this iteration
 #pragma unroll
                     for (int c = 0; c < 2; c++)
@@ -1329,7 +1324,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
             slot = slot + 1 == K ? 0 : slot + 1;
             if constexpr (OUT1) {
                 float m1[2][NPL];
-                hpass(ab_lane, m1);
+                hpass(ab_lane, m1, std::integral_constant<int, HGRP>());
                 float o[2][NPL];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -1337,10 +1332,10 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
                     float dot = 0.0f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        const float mI = fM[c][ch];
+                        const float mI = STATF ? fMn[c][ch] : fM[c][ch];
                         const float mp = mI * meanP;
                         const float cov = m1[c][1 + ch] - mp;
-                        const float ac = (float)((double)cov * fR[c][ch]);
+                        const float ac = (float)((double)cov * (STATF ? fRn[c][ch] : fR[c][ch]));
                         o[c][ch] = ac;
                         const float pr2 = ac * mI;
                         dot = (ch == 0) ? pr2 : dot + pr2;
@@ -1350,6 +1345,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
                 for (int p = 0; p < NPL; p++) *reinterpret_cast<float2*>(xs + p * SW + c0) = make_float2(o[0][p], o[1][p]);
             }
+            if constexpr (STATF) issue_stats(it + 1);
         }
         uint2 fQ = make_uint2(0u, 0u);
         if constexpr (OUT2) {
@@ -1358,7 +1354,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
                 fQ = make_uint2(pq[xqc], pq[xqc + 1]);
             }
         }
-        __syncthreads();
+        __syncthreads();  // (a bare s_waitcnt lgkmcnt(0) + s_barrier, without the fence's vmcnt drain, measured the same)
         if constexpr (HAS2) {
             if (role == 1) {
                 float o[2][NPL];
@@ -1380,7 +1376,7 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
                 slot = slot + 1 == K ? 0 : slot + 1;
                 if constexpr (OUT2) {
                     float m2[2][NPL];
-                    hpass(c0 < XO2, m2);
+                    hpass(c0 < XO2, m2, std::integral_constant<int, 2>());
                     float qv[2];
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
