@@ -67,7 +67,7 @@ struct AswTuning {
     int wmedian_gen_rows = 0;    // ASW_WMEDIAN_GEN_ROWS: block rows per workgroup of the general tile form (windows 17..37): 1 | 2 | 4 | 8
     int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
     int ring_ab = 1, ring_q = 1; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_guided3), 0 = re-fetch
-    int guided_fused = 0;        // ASW_GUIDED_FUSED: 1 = fused a/b -> q walk of the 3-channel guided filter at 15x15 (k_guided_pair3: no a/b volume, a third of the traffic, ~5 % slower)
+    int guided_fused = -1;       // ASW_GUIDED_FUSED: fused a/b -> q walk of GuidedF_2 at 15x15 (k_guided_pair3: no a/b volume, a third of the traffic): 1 always, 0 never, -1 = frames large enough for it (guided_uses_fused)
     int q_wg_strips = 1;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
     void read_environment();
 };
@@ -196,6 +196,8 @@ struct GuidedLaunch {
 };
 size_t guided_stats_floats(int C, int nstat, int H, int W);
 size_t guided_ab_floats(int C, int n, int H, int W, int r);
+// true: launch_guided will run the fused a/b -> q walk for this problem (no a/b scratch is touched)
+bool guided_uses_fused(const AswTuning& t, int C, int guide_per_slice, int shifted, int nan_safe, int H, int W, int n, int r);
 int launch_pack_words(hipStream_t s, const uint8_t* img, int H, int W, int C, int w, uint32_t* out);
 int launch_guided(hipStream_t s, const GuidedLaunch& a);
 

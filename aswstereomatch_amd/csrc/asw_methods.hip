@@ -324,7 +324,9 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     ASW_TRY(psc.ensure((size_t)n * sizeof(float2)));
     ASW_TRY(gsc.ensure((size_t)n * sizeof(float2)));
     ASW_TRY(stats.ensure(guided_stats_floats(C, nstat, H, W) * 4));
-    ASW_TRY(ab.ensure(guided_ab_floats(C, n, H, W, mp.win) * 4));
+    // (GuidedF_2 on large frames runs the fused walk: no a/b volume -- 4.4 GB at 1080p D=128)
+    const bool fused = guided_uses_fused(ctx->tune, C, plain3 ? 0 : 1, 0, ncc ? 1 : 0, H, W, n, mp.win);
+    ASW_TRY(ab.ensure(fused ? 64 : guided_ab_floats(C, n, H, W, mp.win) * 4));
     ASW_TRY(pxa.ensure((plane + 4) * 4));  // + slack: the q pass reads the guide words of a lane's two columns as one pair, the last one may start at column W-1
     ASW_TRY(pxb.ensure((plane + 4) * 4));
     ASW_TRY(f->vol.ensure(plane * n * 4));  // q volume: always needed for the WTA pass

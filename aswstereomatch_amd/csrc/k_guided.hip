@@ -1460,8 +1460,8 @@ int launch_guided3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<SHIFT>&
         if (rc != ASW_OK) return rc;
     }
     if constexpr (!SHIFT) {
-        // ASW_GUIDED_FUSED=1: one fused a/b -> q walk, no a/b volume (a third of the HBM traffic, ~5 % slower: see k_guided_pair3)
-        if (t.guided_fused > 0 && a.r == 15 && !a.nan_safe && nstat == 1 && a.H >= 16) return launch_guided_fused3(s, a, g, sp, t.band_q);
+        // one fused a/b -> q walk, no a/b volume (k_guided_pair3)
+        if (guided_uses_fused(t, 3, nstat > 1, 0, a.nan_safe, a.H, a.W, a.n, a.r)) return launch_guided_fused3(s, a, g, sp, t.band_q);
     }
     const ABTiles at = ab_tiles(a.H, a.W, a.r);
     ABDstP dst{sp, nstat > 1 ? 1 : 0, reinterpret_cast<float2*>(a.ab), at, a.W};
@@ -1612,6 +1612,17 @@ size_t guided_stats_floats(int C, int nstat, int H, int W)
     if (C == 3) return (size_t)nstat * H * W * 9 + 8;  // planar: three f64 + three f32 planes per slot, and room for the pair access at the last pixel
     return (size_t)nstat * H * W * 8 * 3;
 }
+// The fused walk pays 28 warm-up rows per band and 28 halo columns per strip: it matches the two passes when the frame gives
+// it ~10 rounds of tall bands (1080p D=128: 3.64 against 3.73 ms, 4K D=64: 6.97 / 7.03, 720p D=96: 1.49 / 1.49) and loses on small
+// ones (640x360 D=64: 0.33 / 0.27 ms, 1242x375 D=192: 1.63 / 1.37, 1080p D=32: 1.15 / 1.08) -- tools/time_fused_shapes.py.
+bool guided_uses_fused(const AswTuning& t, int C, int guide_per_slice, int shifted, int nan_safe, int H, int W, int n, int r)
+{
+    if (C != 3 || guide_per_slice || shifted || nan_safe || r != 15 || H < 16 || t.guided_fused == 0) return false;
+    if (t.guided_fused > 0) return true;
+    const long long strips = (W + 99) / 100;
+    return strips * n * H >= 2000000LL;
+}
+
 size_t guided_ab_floats(int C, int n, int H, int W, int r)
 {
     if (C == 3) return (size_t)n * ab_tiles(H, W, r).slice_stride * 2 + 8;  // strip-major float2 tiles (ABTiles)
