@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every case before it runs (to identify a faulting one)")
     ap.add_argument("--xq", type=float, default=0.0, help="share of the cases forced into the domain of the xq kernels (classic / geodesic, "
                     "both directions, win 15, 63..300 candidates, widths 64..420 incl. partial and border tiles)")
+    ap.add_argument("--only", default="", help="comma-separated method names: every case is drawn from these only (e.g. guided2 with ASW_GUIDED_FUSED=1 in the environment)")
     ap.add_argument("--wmbig", type=float, default=0.0, help="share of the cases forced to the weighted median at 3x3 .. 13x13 and 17x17 .. 41x41 (general tile form, k_wmedian_tile_gen.hip; per-pixel sort above 37)")
     ap.add_argument("--wm15", type=float, default=0.0, help="share of the cases forced to the 15x15 weighted median (the tile form, k_wmedian_tile.hip)")
     args = ap.parse_args()
@@ -74,6 +75,8 @@ def main():
             L, R = Lp[:, :W], Rp[:, :W]   # non-contiguous views; the oracle wrappers copy them
         method = str(rng.choice(["classic", "direct8", "geodesic", "guided", "guided2", "guided3", "wmedian", "blo1", "ncc", "ncc_cost",
                                 "ad_tad", "similarity", "sad", "geodist", "gfilter", "prep", "bilgrid", "lrcheck", "resident", "batch"]))
+        if args.only:
+            method = str(rng.choice(args.only.split(",")))
         if rng.random() < args.xq:
             method = str(rng.choice(["classic", "geodesic"]))
             H, W = int(rng.integers(1, 10)), int(rng.integers(64, 420))
