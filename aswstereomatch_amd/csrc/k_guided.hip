@@ -1130,9 +1130,11 @@ int launch_walk(hipStream_t s, const Src& src, const Dst& dst, int H, int W, int
 // Borders: a/b at a virtual row / column -k is a/b(k) (BORDER_REFLECT_101 of the second boxFilter); the first stage evaluated at
 // the virtual position sees the mirrored window of position k -- the same multiset of cost samples, summed in f64 in another
 // order -- and takes the statistics of position k, so no border case exists in the walk.
-// NOT the default (ASW_GUIDED_FUSED=1 selects it): 3.66-3.83 ms against 3.42-3.60 ms for the two passes on the same boxes.  A first
-// form with both stages in ONE wavefront (both rings: 284-470 registers, one wavefront per SIMD) took 4.18-5.70 ms; the form
-// below splits the stages over a PAIR of wavefronts.  Results are bit-identical to the two-pass path.
+// Used for frames that give it ~10 rounds of tall bands (guided_uses_fused: 1080p D=128, 4K; ASW_GUIDED_FUSED=0 / 1 force either
+// path): there it runs as fast as the two passes within the spread of the boxes (kernel 3.65-3.83 against 3.42-3.60 ms, whole
+// aggregation by the library's events 3.63 / 3.64 against 3.59 / 3.73 ms on two boxes); on small frames the two passes win.  A
+// first form with both stages in ONE wavefront (both rings: 284-470 registers, one wavefront per SIMD) took 4.18-5.70 ms; the
+// form below splits the stages over a PAIR of wavefronts.  Results are bit-identical to the two-pass path.
 struct FusedArgs {
     GuideAccT<false> g;
     const float* P;          // raw cost volume [n][H][W]
