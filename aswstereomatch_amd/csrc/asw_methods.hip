@@ -386,7 +386,7 @@ static int run_guided(asw_ctx* ctx, Frame* f, const MatchParams& mp, bool keep_v
     ASW_TRY(launch_guided(ctx->stream, a));
     ASW_TRY(launch_wta(ctx->stream, f->vol.as<float>(), n, H, W, mp.minD, f->disp.as<float>()));  // M.cpp:3032-3048
     ASW_HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->timing.aggregate_launches = plain3 ? 4 : 5;
+    ctx->timing.aggregate_launches = plain3 ? (fused ? 3 : 4) : 5;  // statistics, [a/b, q | fused walk], WTA
     return ASW_OK;
 }
 

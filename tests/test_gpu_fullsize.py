@@ -125,11 +125,21 @@ def test_c3_1080p_guided2_whole_frame_vs_oracle(ctx, oracle):
     The WTA map must nevertheless be identical on all 2 073 600 pixels (M.cpp:2976-3050)."""
     L, R, _ = make_pair(1080, 1920, 128, seed=77)
     d, v = ctx.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 128, return_cost_volume=True)
+    # a frame of this size runs the fused a/b -> q walk (k_guided_pair3): statistics, fused walk, WTA
+    assert ctx.timing()["aggregate_launches"] == 3
     rc, dw, vw = oracle.asw_guided2(L, R, 0, 1e-6, 15, 0, 128, want_vol=True)
     assert rc == 0 and vw.shape == v.shape == (128, 1080, 1920)
     frac = _volume_close(v, vw)
     assert frac < 0.05, frac
     assert np.array_equal(d, dw), int((d != dw).sum())
+    # ... and the two-pass path (what smaller frames run) gives the same bits
+    two = asw.Context(0, env={"ASW_GUIDED_FUSED": "0"})
+    try:
+        d2, v2 = two.stereoMatching(L, R, LEFT, A.ADAPTIVE_WEIGHT_GUIDED_FILTER_2, 15, 0, 128, return_cost_volume=True)
+        assert two.timing()["aggregate_launches"] == 4
+    finally:
+        two.close()
+    assert np.array_equal(d2, d) and np.array_equal(v2, v)
 
 
 def test_c3_1080p_guided_whole_frame_vs_oracle(ctx, oracle):
