@@ -83,6 +83,7 @@ void AswTuning::read_environment()
     ring_q = num("ASW_RING_Q", ring_q);
     q_wg_strips = num("ASW_Q_WG_STRIPS", q_wg_strips);
     guided_fused = num("ASW_GUIDED_FUSED", guided_fused);
+    q6_pair = num("ASW_Q6_PAIR", q6_pair);
 }
 
 extern "C" int asw_create(int device_id, asw_ctx** out)

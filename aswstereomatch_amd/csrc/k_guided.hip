@@ -564,7 +564,7 @@ __global__ void k_scale_groups(const float2* __restrict__ scales, int n, int* __
     rep[k] = r;
 }
 
-// a/b planes interleaved per pixel: ab[k][y][x][AS], AS = 4 (C=3) or 8 (C=6): {a_0..a_C-1, b, pad}
+// a/b planes: C = 6: two float4 volumes [half][k][y][x] = {a_0..a_3}, {a_4, a_5, b, pad}
 template <int C> struct ABStride { static constexpr int value = (C == 3) ? 4 : 8; };
 
 // box(P), box(I_c*P) -> a_c = cov_c / den_c, b = meanP - sum_c a_c*meanI_c      (M.cpp:2780-2847)
@@ -620,6 +620,7 @@ struct ABDst {
     StatsSplit sp;
     float* ab;
     int H, W;
+    size_t hstride;  // floats between the two 16-byte halves of a pixel's record: the volume is [half][n][H][W] float4 (see k_q6_pair)
     static constexpr int AS = ABStride<C>::value;
     struct Col { const float* st[C / 3]; float* ab; };  // statistics of every word at this column (slot and shift resolved)
     struct Raw { float4 s[C == 3 ? 2 : 4]; };  // per word: {mean_0..2, den_0}, {den_1, den_2, -, -}
@@ -641,7 +642,7 @@ struct ABDst {
             }
             c.st[w] = base + ((size_t)slot * H * W + xs) * SS8;
         }
-        c.ab = ab + ((size_t)k * H * W + x) * AS;
+        c.ab = ab + ((size_t)k * H * W + x) * 4;
         return c;
     }
     __device__ __forceinline__ Raw fetch(int y, const Col& c) const
@@ -680,9 +681,9 @@ struct ABDst {
             dot = (ch == 0) ? pr : dot + pr;  // operator*(Vec,Vec): left to right (M.cpp:22-31)
         }
         o[C] = meanP - dot;
-        float4* dstp = reinterpret_cast<float4*>(c.ab + (size_t)y * W * AS);
+        float* dstp = c.ab + (size_t)y * W * 4;
 #pragma unroll
-        for (int i = 0; i < AS / 4; i++) dstp[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+        for (int i = 0; i < AS / 4; i++) *reinterpret_cast<float4*>(dstp + i * hstride) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
     }
 };
 
@@ -691,16 +692,17 @@ template <int C>
 struct QSrc {
     const float* ab;
     int H, W;
+    size_t hstride;  // see ABDst
     static constexpr int AS = ABStride<C>::value;
     struct Col { const float* ab; };
     struct Raw { float4 v[AS / 4]; };
-    __device__ __forceinline__ Col col(int x, int k) const { return Col{ab + ((size_t)k * H * W + x) * AS}; }
+    __device__ __forceinline__ Col col(int x, int k) const { return Col{ab + ((size_t)k * H * W + x) * 4}; }
     __device__ __forceinline__ Raw fetch(int y, const Col& c) const
     {
         Raw r;
-        const float4* p = reinterpret_cast<const float4*>(c.ab + (size_t)y * W * AS);
+        const float* p = c.ab + (size_t)y * W * 4;
 #pragma unroll
-        for (int i = 0; i < AS / 4; i++) r.v[i] = p[i];
+        for (int i = 0; i < AS / 4; i++) r.v[i] = *reinterpret_cast<const float4*>(p + i * hstride);
         return r;
     }
     static constexpr int KEEP = AS;
@@ -1429,6 +1431,217 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
     run(iters, T(), T(), T(), T(), T());
 }
 
+// ---- q pass of the 6-channel guide (GuidedF / GuidedF_3), 15x15, finite costs: a PAIR of ring wavefronts per strip ---------------
+// The seven planes {a_0..a_5, b} of a pixel are two 16-byte halves {a_0..a_3}, {a_4, a_5, b, -}, each a dense [n][H][W] float4
+// volume of its own (as ONE 32-byte record, each wavefront of the pair below read every other 16 bytes: 3.40 ms).  A register ring for all of them (224 registers with two
+// columns per lane) does not exist, so k_box_walk fetched the leaving row again and walked 32-row bands to keep that second read
+// in L2 (44 % warm-up rows): 3.7-3.9 ms, memory-bound.  Here wavefront 0 of a pair takes the record's first 16 bytes {a_0..a_3},
+// wavefront 1 the other 16 {a_4, a_5, b, -}: each keeps ITS four planes of the last 15 rows in a register ring (128 registers,
+// nothing is read twice, bands as tall as the launch geometry allows), runs its own column sums and horizontal pass, and the
+// dot product q = sum_c mean(a_c) I_c + mean(b) (left to right, M.cpp:22-31, 2851-2852) is handed from wavefront 0 to wavefront 1
+// through LDS after its fourth term: one workgroup barrier per output row.
+struct Q6Args {
+    GuideAccT<true> g;
+    const float* ab;  // [2][n][H][W] float4: {a_0..a_3} planes, then {a_4, a_5, b, -}
+    float* q;         // [n][H][W]
+    int H, W, n, band, nxw, nby;
+};
+
+template <int PF>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_q6_pair(Q6Args a)
+{
+    constexpr int K = 15, HL = 7, SW = 128, XO = SW - (K - 1), NPL = 4, HP = (K - 1) / 2;
+    constexpr int NPH = PF + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* hs = reinterpret_cast<double*>(smem) + (size_t)role * NPL * (SW + 2);   // [NPL][SW+2] per wavefront
+    float* xch = reinterpret_cast<float*>(smem + 2 * NPL * (SW + 2) * 8);             // [2][SW]: partial dot products, double-buffered
+    const int H = a.H, W = a.W;
+    const int wj = blockIdx.x >> 3;
+    const int nreg = a.nxw * a.nby, rpx = (nreg + 7) >> 3;
+    const int reg = (blockIdx.x & 7) * rpx + wj / a.n;
+    if (wj / a.n >= rpx || reg >= nreg) return;  // whole workgroup
+    const int xw = reg % a.nxw, by = reg / a.nxw;
+    const int kz = wj % a.n;
+    const int xo0 = xw * XO, c0 = 2 * lane;
+    const int y0 = by * a.band, y1 = min(H, y0 + a.band);
+    const size_t plane = (size_t)H * W;
+    const float4* pc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int xi = reflect101_idx(xo0 - HL + c0 + c, W);
+        pc[c] = reinterpret_cast<const float4*>(a.ab) + (size_t)role * a.n * plane + (size_t)kz * plane + xi;  // [half][n][H][W] float4
+    }
+    const int xq = xo0 + c0;
+    const bool reader = c0 < XO, q_lane = reader && xq < W, q_second = c0 + 1 < XO && xq + 1 < W;
+    const typename GuideAccT<true>::Col gcol0 = a.g.col(min(xq, W - 1), kz), gcol1 = a.g.col(min(xq + 1, W - 1), kz);
+    float* qo = a.q + (size_t)kz * plane + min(xq, W - 1);
+    const double scale = 1.0 / ((double)K * (double)K);
+
+    double vs[2][NPL];
+    v16u ring[2][NPL];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int p = 0; p < NPL; p++) { vs[c][p] = 0.0; ring[c][p] = 0; }
+    int slot = 0;
+    const int steps = (y1 - y0) + K - 1;
+
+    float4 fN[NPH][2];
+    auto issue = [&](int s, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
+        const size_t rn = (size_t)reflect101_idx(y0 - HL + s, H) * W;  // in float4 units
+#pragma unroll
+        for (int c = 0; c < 2; c++) fN[SL][c] = pc[c][rn];
+    };
+    if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
+    if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
+
+    auto step = [&](int s, auto ph_c, auto sub_c, auto out_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr bool SUB = decltype(sub_c)::value, OUT = decltype(out_c)::value;
+        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
+        const int y = y0 + s - (K - 1);
+        uint32_t gw[2][2];  // guide words of the two output pixels: [column][word A / B]
+        if constexpr (OUT) {
+            const size_t row = (size_t)y * W;
+            if (role == 0) { gw[0][0] = gcol0.a[row]; gw[1][0] = gcol1.a[row]; }
+            gw[0][1] = gcol0.b[row];
+            gw[1][1] = gcol1.b[row];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float e[NPL] = {fN[PH][c].x, fN[PH][c].y, fN[PH][c].z, fN[PH][c].w};
+#pragma unroll
+            for (int p = 0; p < NPL; p++) {
+                if constexpr (SUB) vs[c][p] = vs[c][p] - (double)__uint_as_float(ring[c][p][slot]);
+                ring[c][p][slot] = __float_as_uint(e[p]);
+                vs[c][p] = vs[c][p] + (double)e[p];
+            }
+        }
+        slot = slot + 1 == K ? 0 : slot + 1;
+        if constexpr (OUT) {
+#pragma unroll
+            for (int p = 0; p < NPL; p++) {
+                hs[p * (SW + 2) + c0] = vs[0][p] + vs[1][p];
+                hs[p * (SW + 2) + c0 + 1] = vs[0][p];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float m[2][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; p++) { m[0][p] = 0.0f; m[1][p] = 0.0f; }
+            if (reader) {
+                constexpr int GRP = 2;
+#pragma unroll
+                for (int p0 = 0; p0 < NPL; p0 += GRP) {
+                    double bb[GRP][2 * HP + 2];
+#pragma unroll
+                    for (int g = 0; g < GRP; g++) {
+                        const double* b = hs + (p0 + g) * (SW + 2) + c0;
+#pragma unroll
+                        for (int i = 2; i < 2 * HP + 2; i++)
+                            if (!(i & 1) || i == 2 * HP + 1) bb[g][i] = b[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < GRP; g++) {
+                        const int p = p0 + g;
+                        double t = bb[g][2];
+#pragma unroll
+                        for (int i = 2; i < HP; i++) t = t + bb[g][2 * i];
+                        const double s0 = ((vs[0][p] + vs[1][p]) + t) + bb[g][2 * HP + 1];
+                        const double s1 = (vs[1][p] + t) + bb[g][2 * HP];
+                        m[0][p] = (float)(s0 * scale);
+                        m[1][p] = (float)(s1 * scale);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float* xs = xch + (s & 1) * SW;
+            const float2 sc[2] = {gcol0.sc, gcol1.sc};
+            if (role == 0) {  // terms 0..3: channels of word A, first channel of word B
+                float part[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float I0 = (float)(gw[c][0] & 0xffu) * sc[c].x + sc[c].y, I1 = (float)((gw[c][0] >> 8) & 0xffu) * sc[c].x + sc[c].y,
+                                I2 = (float)((gw[c][0] >> 16) & 0xffu) * sc[c].x + sc[c].y, I3 = (float)(gw[c][1] & 0xffu) * sc[c].x + sc[c].y;
+                    float dot = m[c][0] * I0;
+                    dot = dot + m[c][1] * I1;
+                    dot = dot + m[c][2] * I2;
+                    dot = dot + m[c][3] * I3;
+                    part[c] = dot;
+                }
+                *reinterpret_cast<float2*>(xs + c0) = make_float2(part[0], part[1]);
+            }
+            __syncthreads();
+            if (role == 1) {  // terms 4, 5 and mean(b)
+                const float2 part = *reinterpret_cast<const float2*>(xs + c0);
+                float qv[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float I4 = (float)((gw[c][1] >> 8) & 0xffu) * sc[c].x + sc[c].y, I5 = (float)((gw[c][1] >> 16) & 0xffu) * sc[c].x + sc[c].y;
+                    float dot = c == 0 ? part.x : part.y;
+                    dot = dot + m[c][0] * I4;
+                    dot = dot + m[c][1] * I5;
+                    qv[c] = dot + m[c][2];
+                }
+                if (q_lane) {
+                    float* o = qo + (size_t)y * W;
+                    if (q_second) {
+                        typedef float v2f __attribute__((ext_vector_type(2)));
+                        const v2f v = {qv[0], qv[1]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(o));
+                    } else {
+                        o[0] = qv[0];
+                    }
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0, ph = 0;
+    auto run = [&](int s_end, auto sub_c, auto out_c) __attribute__((always_inline)) {
+        if constexpr (NPH > 1) { if (ph == 1 && s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2 % NPH; } }
+        if constexpr (NPH > 2) { if (ph == 2 && s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); s++; ph = 0; } }
+        if (ph == 0) {
+            for (; s + NPH <= s_end; s += NPH) {
+                step(s, std::integral_constant<int, 0>(), sub_c, out_c);
+                if constexpr (NPH > 1) step(s + 1, std::integral_constant<int, 1 % NPH>(), sub_c, out_c);
+                if constexpr (NPH > 2) step(s + 2, std::integral_constant<int, 2 % NPH>(), sub_c, out_c);
+            }
+            if constexpr (NPH > 1) { if (s < s_end) { step(s, std::integral_constant<int, 0>(), sub_c, out_c); s++; ph = 1; } }
+            if constexpr (NPH > 2) { if (s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2; } }
+        }
+    };
+    run(min(K - 1, steps), F(), F());
+    run(min(K, steps), F(), T());
+    run(steps, T(), T());
+}
+
+int launch_q6_pair(hipStream_t s, const GuidedLaunch& a, const GuideAccT<true>& g, int band_opt)
+{
+    constexpr int XO = 128 - 14;
+    Q6Args f;
+    f.g = g; f.ab = a.ab; f.q = a.q; f.H = a.H; f.W = a.W; f.n = a.n;
+    f.nxw = (a.W + XO - 1) / XO;
+    // ~10 rounds of the 1024 two-wavefront workgroups the chip holds; 14 warm-up rows per band
+    int nb = (int)std::max<long long>(1, (10240 + (long long)f.nxw * a.n - 1) / ((long long)f.nxw * a.n));
+    nb = std::min(nb, std::max(1, a.H / 30));
+    f.band = band_opt >= 16 ? band_opt : (a.H + nb - 1) / nb;
+    f.nby = (a.H + f.band - 1) / f.band;
+    const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * a.n;
+    if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
+    const size_t lds = 2 * 4 * (128 + 2) * sizeof(double) + 2 * 128 * sizeof(float);
+    hipLaunchKernelGGL(k_q6_pair<2>, dim3((unsigned)nwg), dim3(128), lds, s, f);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
 int launch_guided_fused3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<false>& g, const StatsPlanes& sp, int band_opt)
 {
     constexpr int XO2 = 128 - 28;
@@ -1572,7 +1785,8 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
         if (rc != ASW_OK) return rc;
     }
     ABSrc<6, true> src{g, a.P, a.pscales, a.H, a.W};
-    ABDst<6> dst{sp, a.ab, a.H, a.W};
+    const size_t hstride = (size_t)a.n * a.H * a.W * 4;
+    ABDst<6> dst{sp, a.ab, a.H, a.W, hstride};
     // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
     // (boxes wider than 32 do not leave outputs in a 64-column strip: those take the two-column form at 148 VGPRs)
@@ -1581,7 +1795,8 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     else
         rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1, 4, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
-    QSrc<6> qs{a.ab, a.H, a.W};
+    if (a.r == 15 && !a.nan_safe && a.tune->q6_pair != 0) return launch_q6_pair(s, a, g, a.tune->band_q);
+    QSrc<6> qs{a.ab, a.H, a.W, hstride};
     QDst<6, true> qd{g, a.q, a.H, a.W};
     // two columns per lane: 4.5 ms, one: 5.3 ms.  No load FIFO here (PF = 0): 16 floats per row and lane in flight twice over would
     // cost the fourth wavefront per SIMD (5.1 ms at two)

@@ -1,0 +1,17 @@
+"""k_q6_pair (the 6-channel guide's q pass as a pair of ring wavefronts) against the k_box_walk form (ASW_Q6_PAIR=0): GuidedF volumes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import aswstereomatch_amd as asw
+from aswstereomatch_amd.synth import make_pair
+old = asw.Context(0, env={"ASW_Q6_PAIR": "0"})
+new = asw.Context(0)
+ok = True
+for (H, W, D, dt) in ((40, 64, 8, 0), (33, 230, 12, 0), (100, 333, 20, 1), (16, 100, 4, 0), (61, 1000, 6, 1), (270, 480, 16, 0), (5, 30, 3, 0)):
+    L, R, _ = make_pair(H, W, D, seed=H + W)
+    d0, v0 = old.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, 15, 0, D, return_cost_volume=True)
+    d1, v1 = new.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, 15, 0, D, return_cost_volume=True)
+    err = float(np.max(np.abs(v0 - v1)))
+    print("%4dx%-4d D=%-3d type %d  max abs diff %.3g  bit-equal %s  disparity diffs %d" % (W, H, D, dt, err, np.array_equal(v0, v1), int((d0 != d1).sum())), flush=True)
+    ok = ok and err < 1e-5
+print("OK" if ok else "MISMATCH")
