@@ -682,8 +682,9 @@ struct ABDst {
         }
         o[C] = meanP - dot;
         float* dstp = c.ab + (size_t)y * W * 4;
-#pragma unroll
-        for (int i = 0; i < AS / 4; i++) *reinterpret_cast<float4*>(dstp + i * hstride) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+        static_assert(C == 6, "halves {a_0, a_1, a_2, -} and {a_3, a_4, a_5, b}: one per guide word (k_ab6_pair / k_q6_pair)");
+        *reinterpret_cast<float4*>(dstp) = make_float4(o[0], o[1], o[2], 0.0f);
+        *reinterpret_cast<float4*>(dstp + hstride) = make_float4(o[3], o[4], o[5], o[6]);
     }
 };
 
@@ -729,8 +730,8 @@ struct QSrc {
         float t[AS];
 #pragma unroll
         for (int i = 0; i < AS / 4; i++) { t[4 * i] = r.v[i].x; t[4 * i + 1] = r.v[i].y; t[4 * i + 2] = r.v[i].z; t[4 * i + 3] = r.v[i].w; }
-#pragma unroll
-        for (int ch = 0; ch < C + 1; ch++) v[ch] = t[ch];
+        static_assert(C == 6, "see ABDst::emit");
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[4]; v[4] = t[5]; v[5] = t[6]; v[6] = t[7];
     }
 };
 template <int C, bool SHIFT>
@@ -1432,17 +1433,17 @@ __global__ __launch_bounds__(128 * NPAIR) __attribute__((amdgpu_waves_per_eu(2, 
 }
 
 // ---- q pass of the 6-channel guide (GuidedF / GuidedF_3), 15x15, finite costs: a PAIR of ring wavefronts per strip ---------------
-// The seven planes {a_0..a_5, b} of a pixel are two 16-byte halves {a_0..a_3}, {a_4, a_5, b, -}, each a dense [n][H][W] float4
+// The seven planes {a_0..a_5, b} of a pixel are two 16-byte halves {a_0, a_1, a_2, -}, {a_3, a_4, a_5, b} -- one per guide word --, each a dense [n][H][W] float4
 // volume of its own (as ONE 32-byte record, each wavefront of the pair below read every other 16 bytes: 3.40 ms).  A register ring for all of them (224 registers with two
 // columns per lane) does not exist, so k_box_walk fetched the leaving row again and walked 32-row bands to keep that second read
-// in L2 (44 % warm-up rows): 3.7-3.9 ms, memory-bound.  Here wavefront 0 of a pair takes the record's first 16 bytes {a_0..a_3},
-// wavefront 1 the other 16 {a_4, a_5, b, -}: each keeps ITS four planes of the last 15 rows in a register ring (128 registers,
+// in L2 (44 % warm-up rows): 3.7-3.9 ms, memory-bound.  Here wavefront 0 of a pair takes the first half {a_0, a_1, a_2},
+// wavefront 1 the other 16 {a_3, a_4, a_5, b}: each keeps ITS four planes of the last 15 rows in a register ring (128 registers,
 // nothing is read twice, bands as tall as the launch geometry allows), runs its own column sums and horizontal pass, and the
 // dot product q = sum_c mean(a_c) I_c + mean(b) (left to right, M.cpp:22-31, 2851-2852) is handed from wavefront 0 to wavefront 1
-// through LDS after its fourth term: one workgroup barrier per output row.
+// through LDS after its third term: one workgroup barrier per output row.  A wavefront needs only ITS guide word.
 struct Q6Args {
     GuideAccT<true> g;
-    const float* ab;  // [2][n][H][W] float4: {a_0..a_3} planes, then {a_4, a_5, b, -}
+    const float* ab;  // [2][n][H][W] float4: {a_0, a_1, a_2, -} planes, then {a_3, a_4, a_5, b}
     float* q;         // [n][H][W]
     int H, W, n, band, nxw, nby;
 };
@@ -1502,12 +1503,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr bool SUB = decltype(sub_c)::value, OUT = decltype(out_c)::value;
         issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
         const int y = y0 + s - (K - 1);
-        uint32_t gw[2][2];  // guide words of the two output pixels: [column][word A / B]
+        uint32_t gw[2][1];  // this wavefront's guide word of the two output pixels
         if constexpr (OUT) {
             const size_t row = (size_t)y * W;
-            if (role == 0) { gw[0][0] = gcol0.a[row]; gw[1][0] = gcol1.a[row]; }
-            gw[0][1] = gcol0.b[row];
-            gw[1][1] = gcol1.b[row];
+            gw[0][0] = role == 0 ? gcol0.a[row] : gcol0.b[row];  // every wavefront needs ITS guide word only
+            gw[1][0] = role == 0 ? gcol1.a[row] : gcol1.b[row];
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -1563,31 +1563,35 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float* xs = xch + (s & 1) * SW;
             const float2 sc[2] = {gcol0.sc, gcol1.sc};
-            if (role == 0) {  // terms 0..3: channels of word A, first channel of word B
+            float I[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                I[c][0] = (float)(gw[c][0] & 0xffu) * sc[c].x + sc[c].y;
+                I[c][1] = (float)((gw[c][0] >> 8) & 0xffu) * sc[c].x + sc[c].y;
+                I[c][2] = (float)((gw[c][0] >> 16) & 0xffu) * sc[c].x + sc[c].y;
+            }
+            if (role == 0) {  // terms 0..2: word A
                 float part[2];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const float I0 = (float)(gw[c][0] & 0xffu) * sc[c].x + sc[c].y, I1 = (float)((gw[c][0] >> 8) & 0xffu) * sc[c].x + sc[c].y,
-                                I2 = (float)((gw[c][0] >> 16) & 0xffu) * sc[c].x + sc[c].y, I3 = (float)(gw[c][1] & 0xffu) * sc[c].x + sc[c].y;
-                    float dot = m[c][0] * I0;
-                    dot = dot + m[c][1] * I1;
-                    dot = dot + m[c][2] * I2;
-                    dot = dot + m[c][3] * I3;
+                    float dot = m[c][0] * I[c][0];
+                    dot = dot + m[c][1] * I[c][1];
+                    dot = dot + m[c][2] * I[c][2];
                     part[c] = dot;
                 }
                 *reinterpret_cast<float2*>(xs + c0) = make_float2(part[0], part[1]);
             }
             __syncthreads();
-            if (role == 1) {  // terms 4, 5 and mean(b)
+            if (role == 1) {  // terms 3..5: word B, then mean(b)
                 const float2 part = *reinterpret_cast<const float2*>(xs + c0);
                 float qv[2];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const float I4 = (float)((gw[c][1] >> 8) & 0xffu) * sc[c].x + sc[c].y, I5 = (float)((gw[c][1] >> 16) & 0xffu) * sc[c].x + sc[c].y;
                     float dot = c == 0 ? part.x : part.y;
-                    dot = dot + m[c][0] * I4;
-                    dot = dot + m[c][1] * I5;
-                    qv[c] = dot + m[c][2];
+                    dot = dot + m[c][0] * I[c][0];
+                    dot = dot + m[c][1] * I[c][1];
+                    dot = dot + m[c][2] * I[c][2];
+                    qv[c] = dot + m[c][3];
                 }
                 if (q_lane) {
                     float* o = qo + (size_t)y * W;
