@@ -84,6 +84,7 @@ void AswTuning::read_environment()
     q_wg_strips = num("ASW_Q_WG_STRIPS", q_wg_strips);
     guided_fused = num("ASW_GUIDED_FUSED", guided_fused);
     q6_pair = num("ASW_Q6_PAIR", q6_pair);
+    ab6_pair = num("ASW_AB6_PAIR", ab6_pair);
 }
 
 extern "C" int asw_create(int device_id, asw_ctx** out)

@@ -68,6 +68,7 @@ struct AswTuning {
     int band_ab = 0, band_q = 0; // ASW_BAND_AB / ASW_BAND_Q: rows per band of the guided filter's passes
     int ring_ab = 1, ring_q = 1; // ASW_RING_AB / ASW_RING_Q: register-ring form of the two passes (k_guided.hip: launch_guided3), 0 = re-fetch
     int guided_fused = -1;       // ASW_GUIDED_FUSED: fused a/b -> q walk of GuidedF_2 at 15x15 (k_guided_pair3: no a/b volume, a third of the traffic): 1 always, 0 never, -1 = frames large enough for it (guided_uses_fused)
+    int ab6_pair = -1;           // ASW_AB6_PAIR: 0 = the a/b pass of the 6-channel guide through k_box_walk instead of k_ab6_pair
     int q6_pair = -1;            // ASW_Q6_PAIR: 0 = the q pass of the 6-channel guide through k_box_walk (re-fetching form) instead of k_q6_pair
     int q_wg_strips = 1;         // ASW_Q_WG_STRIPS: workgroup of the q pass = 4 neighbouring strips (1) / 4 slices of a strip (0)
     void read_environment();

@@ -1646,6 +1646,264 @@ int launch_q6_pair(hipStream_t s, const GuidedLaunch& a, const GuideAccT<true>& 
     return ASW_OK;
 }
 
+// ---- a/b pass of the 6-channel guide (GuidedF), 15x15, finite costs: a PAIR of wavefronts per strip, one per guide word ---------
+// k_box_walk evaluates the seven plane sums {P, I_0 P .. I_5 P} of a column in one wavefront: one column per lane (two need 168
+// registers), no pair sums, 32-row bands because the leaving row is fetched again -- 5.3 ms, VALU-bound (2.0e9 instructions).
+// Here wavefront w of a pair takes guide word w: planes {P, I_3w P, I_3w+1 P, I_3w+2 P} -- the walk of the 3-channel filter: two
+// columns per lane, pair sums, {cost, guide word} of the last 15 rows in a register ring, tall bands --, computes its three a_c
+// from its word's statistics, and the dot product sum_c a_c meanI_c (left to right over the six channels, M.cpp:22-31, 2847) is
+// handed from wavefront 0 to wavefront 1 through LDS after the third term; wavefront 1 finishes b.  Each writes its 16-byte half
+// of the a/b volume ({a_0, a_1, a_2, -} / {a_3, a_4, a_5, b}).  The P plane is summed by both: 8 plane sums instead of 7.
+struct AB6Args {
+    GuideAccT<true> g;
+    const float* P;
+    const float2* pscales;
+    StatsSplit sp;
+    float* ab;  // [2][n][H][W] float4
+    int H, W, n, band, nxw, nby;
+};
+
+template <int PF, int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_ab6_pair(AB6Args a)
+{
+    constexpr int K = 15, HL = 7, SW = 128, XO = SW - (K - 1), NPL = 4, HP = (K - 1) / 2;
+    constexpr int NPH = PF + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* hs = reinterpret_cast<double*>(smem) + (size_t)role * NPL * (SW + 2);
+    float* xch = reinterpret_cast<float*>(smem + 2 * NPL * (SW + 2) * 8);  // [2][SW] partial dot products
+    const int H = a.H, W = a.W;
+    const int wj = blockIdx.x >> 3;
+    const int nreg = a.nxw * a.nby, rpx = (nreg + 7) >> 3;
+    const int reg = (blockIdx.x & 7) * rpx + wj / a.n;
+    if (wj / a.n >= rpx || reg >= nreg) return;  // whole workgroup
+    const int xw = reg % a.nxw, by = reg / a.nxw;
+    const int kz = wj % a.n;
+    const int xo0 = xw * XO, c0 = 2 * lane;
+    const int y0 = by * a.band, y1 = min(H, y0 + a.band);
+    const size_t plane = (size_t)H * W;
+    const float* pc[2];
+    const uint32_t* gc[2];
+    const float* st[2];  // statistics of this wavefront's word at the lane's two output columns (slot and shift resolved, see ABDst)
+    float2 gsc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int xi = reflect101_idx(xo0 - HL + c0 + c, W);
+        const typename GuideAccT<true>::Col gcol = a.g.col(xi, kz);
+        pc[c] = a.P + (size_t)kz * plane + xi;
+        gc[c] = role == 0 ? gcol.a : gcol.b;
+        gsc = gcol.sc;
+        const int x = min(xo0 + c0 + c, W - 1);
+        const float* base = a.sp.half[role];
+        int slot = a.sp.per_slice ? kz : 0, xs = x;
+        if (a.sp.rep) {
+            if (role != a.sp.shifted) {
+                slot = a.sp.rep[kz];
+            } else if (a.sp.interior(x, kz)) {
+                base = a.sp.unshifted;
+                slot = a.sp.rep[kz];
+                xs = x + a.sp.sgn * (a.sp.minD + kz);
+            }
+        }
+        st[c] = base + ((size_t)slot * plane + xs) * SS8;
+    }
+    const int xq = xo0 + c0;
+    const bool reader = c0 < XO, o_lane = reader && xq < W, o_second = c0 + 1 < XO && xq + 1 < W;
+    float* abo = a.ab + (size_t)role * a.n * plane * 4 + ((size_t)kz * plane + min(xq, W - 1)) * 4;
+    const float2 psc = a.pscales[kz];
+    const double scale = 1.0 / ((double)K * (double)K);
+
+    double vs[2][NPL];
+    v16u ring[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int p = 0; p < NPL; p++) vs[c][p] = 0.0;
+        ring[c][0] = 0; ring[c][1] = 0;
+    }
+    int slot = 0;
+    const int steps = (y1 - y0) + K - 1;
+
+    float fP[NPH][2];
+    uint32_t fG[NPH][2];
+    auto issue = [&](int s, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
+        const size_t rn = (size_t)reflect101_idx(y0 - HL + s, H) * W;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            fP[SL][c] = pc[c][rn];
+            fG[SL][c] = gc[c][rn];
+        }
+    };
+    if constexpr (PF >= 1) issue(0, std::integral_constant<int, 0>());
+    if constexpr (PF >= 2) issue(1, std::integral_constant<int, 1>());
+    auto guide = [&](uint32_t u, float (&I)[3]) __attribute__((always_inline)) {
+        I[0] = (float)(u & 0xffu) * gsc.x + gsc.y;
+        I[1] = (float)((u >> 8) & 0xffu) * gsc.x + gsc.y;
+        I[2] = (float)((u >> 16) & 0xffu) * gsc.x + gsc.y;
+    };
+
+    auto step = [&](int s, auto ph_c, auto sub_c, auto out_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr bool SUB = decltype(sub_c)::value, OUT = decltype(out_c)::value;
+        issue(s + PF, std::integral_constant<int, (PH + PF) % NPH>());
+        const int y = y0 + s - (K - 1);
+        float4 sa[2], sb[2];  // {mean_0..2, den_0}, {den_1, den_2, -, -} of the output row
+        if constexpr (OUT) {
+            const size_t row = (size_t)y * W * SS8;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float4* p = reinterpret_cast<const float4*>(st[c] + row);
+                sa[c] = p[0];
+                sb[c] = p[1];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if constexpr (SUB) {
+                const float po = __uint_as_float(ring[c][0][slot]) * psc.x + psc.y;
+                float Io[3];
+                guide(ring[c][1][slot], Io);
+                vs[c][0] = vs[c][0] - (double)po;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) vs[c][1 + ch] = vs[c][1 + ch] - (double)(Io[ch] * po);
+            }
+            ring[c][0][slot] = __float_as_uint(fP[PH][c]);
+            ring[c][1][slot] = fG[PH][c];
+            const float pn = fP[PH][c] * psc.x + psc.y;
+            float In[3];
+            guide(fG[PH][c], In);
+            vs[c][0] = vs[c][0] + (double)pn;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) vs[c][1 + ch] = vs[c][1 + ch] + (double)(In[ch] * pn);
+        }
+        slot = slot + 1 == K ? 0 : slot + 1;
+        if constexpr (OUT) {
+#pragma unroll
+            for (int p = 0; p < NPL; p++) {
+                hs[p * (SW + 2) + c0] = vs[0][p] + vs[1][p];
+                hs[p * (SW + 2) + c0 + 1] = vs[0][p];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float m[2][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; p++) { m[0][p] = 0.0f; m[1][p] = 0.0f; }
+            if (reader) {
+                constexpr int GRP = 2;
+#pragma unroll
+                for (int p0 = 0; p0 < NPL; p0 += GRP) {
+                    double bb[GRP][2 * HP + 2];
+#pragma unroll
+                    for (int g = 0; g < GRP; g++) {
+                        const double* b = hs + (p0 + g) * (SW + 2) + c0;
+#pragma unroll
+                        for (int i = 2; i < 2 * HP + 2; i++)
+                            if (!(i & 1) || i == 2 * HP + 1) bb[g][i] = b[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < GRP; g++) {
+                        const int p = p0 + g;
+                        double t = bb[g][2];
+#pragma unroll
+                        for (int i = 2; i < HP; i++) t = t + bb[g][2 * i];
+                        const double s0 = ((vs[0][p] + vs[1][p]) + t) + bb[g][2 * HP + 1];
+                        const double s1 = (vs[1][p] + t) + bb[g][2 * HP];
+                        m[0][p] = (float)(s0 * scale);
+                        m[1][p] = (float)(s1 * scale);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // a_c = cov_c / den_c of this word (M.cpp:2796-2846), the partial dot product in the reference's order
+            float o[2][4], dotp[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float mean[3] = {sa[c].x, sa[c].y, sa[c].z}, den[3] = {sa[c].w, sb[c].x, sb[c].y};
+                const float meanP = m[c][0];
+                float dot = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float mp = mean[ch] * meanP;
+                    const float cov = m[c][1 + ch] - mp;
+                    const float ac = cov / den[ch];
+                    o[c][ch] = ac;
+                    const float pr = ac * mean[ch];
+                    dot = (ch == 0) ? pr : dot + pr;  // wavefront 1 re-associates below: its terms are ADDED to wavefront 0's sum one by one
+                }
+                dotp[c] = dot;
+                o[c][3] = 0.0f;
+            }
+            float* xs = xch + (s & 1) * SW;
+            if (role == 0) *reinterpret_cast<float2*>(xs + c0) = make_float2(dotp[0], dotp[1]);
+            __syncthreads();
+            if (role == 1) {
+                const float2 part = *reinterpret_cast<const float2*>(xs + c0);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float mean[3] = {sa[c].x, sa[c].y, sa[c].z};
+                    float dot = c == 0 ? part.x : part.y;  // ((p0 + p1) + p2), then + p3 + p4 + p5 left to right
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) dot = dot + o[c][ch] * mean[ch];
+                    o[c][3] = m[c][0] - dot;  // b = meanP - dot
+                }
+            }
+            if (o_lane) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                float* dst = abo + (size_t)y * W * 4;
+                const v4f v0 = {o[0][0], o[0][1], o[0][2], o[0][3]};
+                __builtin_nontemporal_store(v0, reinterpret_cast<v4f*>(dst));
+                if (o_second) {
+                    const v4f v1 = {o[1][0], o[1][1], o[1][2], o[1][3]};
+                    __builtin_nontemporal_store(v1, reinterpret_cast<v4f*>(dst + 4));
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0, ph = 0;
+    auto run = [&](int s_end, auto sub_c, auto out_c) __attribute__((always_inline)) {
+        if constexpr (NPH > 1) { if (ph == 1 && s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2 % NPH; } }
+        if constexpr (NPH > 2) { if (ph == 2 && s < s_end) { step(s, std::integral_constant<int, 2 % NPH>(), sub_c, out_c); s++; ph = 0; } }
+        if (ph == 0) {
+            for (; s + NPH <= s_end; s += NPH) {
+                step(s, std::integral_constant<int, 0>(), sub_c, out_c);
+                if constexpr (NPH > 1) step(s + 1, std::integral_constant<int, 1 % NPH>(), sub_c, out_c);
+                if constexpr (NPH > 2) step(s + 2, std::integral_constant<int, 2 % NPH>(), sub_c, out_c);
+            }
+            if constexpr (NPH > 1) { if (s < s_end) { step(s, std::integral_constant<int, 0>(), sub_c, out_c); s++; ph = 1; } }
+            if constexpr (NPH > 2) { if (s < s_end) { step(s, std::integral_constant<int, 1 % NPH>(), sub_c, out_c); s++; ph = 2; } }
+        }
+    };
+    run(min(K - 1, steps), F(), F());
+    run(min(K, steps), F(), T());
+    run(steps, T(), T());
+}
+
+int launch_ab6_pair(hipStream_t s, const GuidedLaunch& a, const GuideAccT<true>& g, const StatsSplit& sp, int band_opt)
+{
+    constexpr int XO = 128 - 14;
+    AB6Args f;
+    f.g = g; f.P = a.P; f.pscales = a.pscales; f.sp = sp; f.ab = a.ab; f.H = a.H; f.W = a.W; f.n = a.n;
+    f.nxw = (a.W + XO - 1) / XO;
+    int nb = (int)std::max<long long>(1, (10240 + (long long)f.nxw * a.n - 1) / ((long long)f.nxw * a.n));
+    nb = std::min(nb, std::max(1, a.H / 30));
+    f.band = band_opt >= 16 ? band_opt : (a.H + nb - 1) / nb;
+    f.nby = (a.H + f.band - 1) / f.band;
+    const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * a.n;
+    if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
+    const size_t lds = 2 * 4 * (128 + 2) * sizeof(double) + 2 * 128 * sizeof(float);
+    // register target of three wavefronts per SIMD (168, 4 spilled): 4.38 against 4.65 ms at two (172); pipeline depth 2: 4.67
+    hipLaunchKernelGGL((k_ab6_pair<1, 3>), dim3((unsigned)nwg), dim3(128), lds, s, f);
+    ASW_HIP_TRY(hipGetLastError());
+    return ASW_OK;
+}
+
 int launch_guided_fused3(hipStream_t s, const GuidedLaunch& a, const GuideAccT<false>& g, const StatsPlanes& sp, int band_opt)
 {
     constexpr int XO2 = 128 - 28;
@@ -1794,7 +2052,9 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
     // (boxes wider than 32 do not leave outputs in a 64-column strip: those take the two-column form at 148 VGPRs)
-    if (a.r > 32)
+    if (a.r == 15 && !a.nan_safe && a.tune->ab6_pair != 0)
+        rc = launch_ab6_pair(s, a, g, sp, a.tune->band_ab);
+    else if (a.r > 32)
         rc = a.nan_safe ? launch_walk_t<7, 2, 1, 3, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 3, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     else
         rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1, 4, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);

@@ -1,10 +1,10 @@
-"""k_q6_pair (the 6-channel guide's q pass as a pair of ring wavefronts) against the k_box_walk form (ASW_Q6_PAIR=0): GuidedF volumes."""
+"""k_ab6_pair + k_q6_pair (the 6-channel guide: each pass as a pair of wavefronts, one per guide word) against the k_box_walk forms (ASW_AB6_PAIR=0 ASW_Q6_PAIR=0): GuidedF volumes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aswstereomatch_amd as asw
 from aswstereomatch_amd.synth import make_pair
-old = asw.Context(0, env={"ASW_Q6_PAIR": "0"})
+old = asw.Context(0, env={"ASW_Q6_PAIR": "0", "ASW_AB6_PAIR": "0"})
 new = asw.Context(0)
 ok = True
 for (H, W, D, dt) in ((40, 64, 8, 0), (33, 230, 12, 0), (100, 333, 20, 1), (16, 100, 4, 0), (61, 1000, 6, 1), (270, 480, 16, 0), (5, 30, 3, 0)):
