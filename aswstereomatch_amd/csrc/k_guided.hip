@@ -1708,8 +1708,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         st[c] = base + ((size_t)slot * plane + xs) * SS8;
     }
     const int xq = xo0 + c0;
-    const bool reader = c0 < XO, o_lane = reader && xq < W, o_second = c0 + 1 < XO && xq + 1 < W;
-    float* abo = a.ab + (size_t)role * a.n * plane * 4 + ((size_t)kz * plane + min(xq, W - 1)) * 4;
+    const bool reader = c0 < XO;
+    (void)xq;
+    float* abo_row0 = a.ab + (size_t)role * a.n * plane * 4 + ((size_t)kz * plane + xo0) * 4;  // the strip's first output pixel, row 0
     const float2 psc = a.pscales[kz];
     const double scale = 1.0 / ((double)K * (double)K);
 
@@ -1852,15 +1853,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     o[c][3] = m[c][0] - dot;  // b = meanP - dot
                 }
             }
-            if (o_lane) {
+            // A lane holds two ADJACENT pixels: stored from here, an instruction would cover every other 16 bytes (as nontemporal
+            // stores the halves of each 32-byte piece went out separately: 12.4 GB written for an 8.5 GB volume; as plain stores
+            // the pass took 5.0-5.3 instead of 4.4 ms).  So the strip's 128 results are transposed through the (now idle) LDS strip:
+            // instruction k then writes pixels 64 k + lane -- one dense kilobyte.
+            {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                float* dst = abo + (size_t)y * W * 4;
-                const v4f v0 = {o[0][0], o[0][1], o[0][2], o[0][3]};
-                __builtin_nontemporal_store(v0, reinterpret_cast<v4f*>(dst));
-                if (o_second) {
-                    const v4f v1 = {o[1][0], o[1][1], o[1][2], o[1][3]};
-                    __builtin_nontemporal_store(v1, reinterpret_cast<v4f*>(dst + 4));
-                }
+                v4f* tr = reinterpret_cast<v4f*>(hs);
+                tr[c0] = v4f{o[0][0], o[0][1], o[0][2], o[0][3]};
+                tr[c0 + 1] = v4f{o[1][0], o[1][1], o[1][2], o[1][3]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const v4f w0 = tr[lane], w1 = tr[64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float* dst = abo_row0 + (size_t)y * W * 4;
+                if (xo0 + lane < W) __builtin_nontemporal_store(w0, reinterpret_cast<v4f*>(dst + 4 * lane));
+                if (64 + lane < XO && xo0 + 64 + lane < W) __builtin_nontemporal_store(w1, reinterpret_cast<v4f*>(dst + 4 * (64 + lane)));
             }
         }
     };
