@@ -386,3 +386,24 @@ def test_guided2_fused_walk_equals_two_pass_path(oracle):
     finally:
         base.close()
         fused.close()
+
+
+def test_guided6_pair_kernels_equal_box_walk_passes(oracle):
+    """GuidedF at 15x15: the wavefront-pair kernels (k_ab6_pair / k_q6_pair: one wavefront per guide word, the dot products handed
+    over through LDS in the reference's left-to-right order) against the k_box_walk passes (ASW_AB6_PAIR=0 ASW_Q6_PAIR=0): bit for
+    bit in both directions, each pass switched separately, and against the oracle within the volume tolerance."""
+    new = asw.Context(0)
+    olds = [asw.Context(0, env=e) for e in ({"ASW_AB6_PAIR": "0", "ASW_Q6_PAIR": "0"}, {"ASW_AB6_PAIR": "0"}, {"ASW_Q6_PAIR": "0"})]
+    try:
+        for (H, W, D, dt, seed) in ((16, 40, 5, LEFT, 1), (37, 130, 9, RIGHT, 2), (75, 231, 12, LEFT, 3), (20, 301, 4, RIGHT, 4), (3, 17, 2, LEFT, 5)):
+            L, R, _ = make_pair(H, W, D, seed=seed)
+            d1, v1 = new.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, 15, 0, D, return_cost_volume=True)
+            for c in olds:
+                d0, v0 = c.computeAdaptiveWeight_GuidedF(L, R, dt, 1e-6, 15, 0, D, return_cost_volume=True)
+                assert np.array_equal(d0, d1) and np.array_equal(v0, v1)
+            rc, dw, vw = oracle.asw_guided(L, R, int(dt), 1e-6, 15, 0, D, want_vol=True)
+            assert rc == 0 and np.abs(v1 - vw).max() < 1e-4 and np.array_equal(d1, dw)
+    finally:
+        new.close()
+        for c in olds:
+            c.close()
