@@ -253,7 +253,16 @@ __global__ __launch_bounds__(256) void k_slice_minmax(const float* __restrict__ 
     };
     if ((plane & 3) == 0) {
         const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane / 4; i += stride) {
+        const size_t n4 = plane / 4;
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {  // four loads in flight per thread (one: 3.4 TB/s of the ~6 a read stream reaches)
+            const float4 v0 = p4[i], v1 = p4[i + stride], v2 = p4[i + 2 * stride], v3 = p4[i + 3 * stride];
+            take(v0.x); take(v0.y); take(v0.z); take(v0.w);
+            take(v1.x); take(v1.y); take(v1.z); take(v1.w);
+            take(v2.x); take(v2.y); take(v2.z); take(v2.w);
+            take(v3.x); take(v3.y); take(v3.z); take(v3.w);
+        }
+        for (; i < n4; i += stride) {
             float4 v = p4[i];
             take(v.x); take(v.y); take(v.z); take(v.w);
         }
