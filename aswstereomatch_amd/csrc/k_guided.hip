@@ -1448,7 +1448,7 @@ struct Q6Args {
     int H, W, n, band, nxw, nby;
 };
 
-template <int PF>
+template <int PF, bool NANSAFE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_q6_pair(Q6Args a)
 {
     constexpr int K = 15, HL = 7, SW = 128, XO = SW - (K - 1), NPL = 4, HP = (K - 1) / 2;
@@ -1520,6 +1520,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         slot = slot + 1 == K ? 0 : slot + 1;
+        if constexpr (NANSAFE && OUT) {
+            // a sliding sum never loses a NaN / inf once it has entered: rebuild a poisoned one from the 15 rows of its window, which
+            // the ring holds (oldest first: slot now points at it) -- finite data never takes the branch (see k_box_walk)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                bool poisoned = false;
+#pragma unroll
+                for (int p = 0; p < NPL; p++) poisoned = poisoned || !__builtin_isfinite(vs[c][p]);
+                if (poisoned) {
+                    double acc[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) acc[p] = 0.0;
+                    int idx = slot;
+                    for (int j = 0; j < K; j++) {
+#pragma unroll
+                        for (int p = 0; p < NPL; p++) acc[p] = acc[p] + (double)__uint_as_float(ring[c][p][idx]);
+                        idx = idx + 1 == K ? 0 : idx + 1;
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) vs[c][p] = acc[p];
+                }
+            }
+        }
         if constexpr (OUT) {
 #pragma unroll
             for (int p = 0; p < NPL; p++) {
@@ -1641,7 +1664,10 @@ int launch_q6_pair(hipStream_t s, const GuidedLaunch& a, const GuideAccT<true>& 
     const long long nwg = (long long)((f.nxw * f.nby + 7) / 8) * 8 * a.n;
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
     const size_t lds = 2 * 4 * (128 + 2) * sizeof(double) + 2 * 128 * sizeof(float);
-    hipLaunchKernelGGL(k_q6_pair<2>, dim3((unsigned)nwg), dim3(128), lds, s, f);
+    if (a.nan_safe)
+        hipLaunchKernelGGL((k_q6_pair<2, true>), dim3((unsigned)nwg), dim3(128), lds, s, f);
+    else
+        hipLaunchKernelGGL((k_q6_pair<2, false>), dim3((unsigned)nwg), dim3(128), lds, s, f);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
@@ -1663,7 +1689,7 @@ struct AB6Args {
     int H, W, n, band, nxw, nby;
 };
 
-template <int PF, int WPE>
+template <int PF, int WPE, bool NANSAFE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_ab6_pair(AB6Args a)
 {
     constexpr int K = 15, HL = 7, SW = 128, XO = SW - (K - 1), NPL = 4, HP = (K - 1) / 2;
@@ -1779,6 +1805,31 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             for (int ch = 0; ch < 3; ch++) vs[c][1 + ch] = vs[c][1 + ch] + (double)(In[ch] * pn);
         }
         slot = slot + 1 == K ? 0 : slot + 1;
+        if constexpr (NANSAFE && OUT) {  // see k_q6_pair: the window's 15 rows {cost, guide word} are in the ring, oldest at `slot`
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                bool poisoned = false;
+#pragma unroll
+                for (int p = 0; p < NPL; p++) poisoned = poisoned || !__builtin_isfinite(vs[c][p]);
+                if (poisoned) {
+                    double acc[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) acc[p] = 0.0;
+                    int idx = slot;
+                    for (int j = 0; j < K; j++) {
+                        const float pw = __uint_as_float(ring[c][0][idx]) * psc.x + psc.y;
+                        float Iw[3];
+                        guide(ring[c][1][idx], Iw);
+                        acc[0] = acc[0] + (double)pw;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) acc[1 + ch] = acc[1 + ch] + (double)(Iw[ch] * pw);
+                        idx = idx + 1 == K ? 0 : idx + 1;
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) vs[c][p] = acc[p];
+                }
+            }
+        }
         if constexpr (OUT) {
 #pragma unroll
             for (int p = 0; p < NPL; p++) {
@@ -1910,7 +1961,10 @@ int launch_ab6_pair(hipStream_t s, const GuidedLaunch& a, const GuideAccT<true>&
     if (nwg > 0x7fffffffLL) return ASW_ERR_BAD_ARGUMENT;
     const size_t lds = 2 * 4 * (128 + 2) * sizeof(double) + 2 * 128 * sizeof(float);
     // register target of three wavefronts per SIMD (168, 4 spilled): 4.38 against 4.65 ms at two (172); pipeline depth 2: 4.67
-    hipLaunchKernelGGL((k_ab6_pair<1, 3>), dim3((unsigned)nwg), dim3(128), lds, s, f);
+    if (a.nan_safe)
+        hipLaunchKernelGGL((k_ab6_pair<1, 3, true>), dim3((unsigned)nwg), dim3(128), lds, s, f);
+    else
+        hipLaunchKernelGGL((k_ab6_pair<1, 3, false>), dim3((unsigned)nwg), dim3(128), lds, s, f);
     ASW_HIP_TRY(hipGetLastError());
     return ASW_OK;
 }
@@ -2063,14 +2117,14 @@ int launch_guided(hipStream_t s, const GuidedLaunch& a)
     // one column per lane for the 7-plane a/b pass (6.2 ms): two columns need 128 VGPRs + 33 spilled (9.3 ms); two columns at a
     // 3-waves-per-SIMD register target (148 VGPRs, no spills) take the same time as one column (GuidedF 12.67 vs 12.60 ms)
     // (boxes wider than 32 do not leave outputs in a 64-column strip: those take the two-column form at 148 VGPRs)
-    if (a.r == 15 && !a.nan_safe && a.tune->ab6_pair != 0)
+    if (a.r == 15 && a.tune->ab6_pair != 0)
         rc = launch_ab6_pair(s, a, g, sp, a.tune->band_ab);
     else if (a.r > 32)
         rc = a.nan_safe ? launch_walk_t<7, 2, 1, 3, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 2, 1, 3, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     else
         rc = a.nan_safe ? launch_walk_t<7, 1, 1, 4, true, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n) : launch_walk_t<7, 1, 1, 4, false, 0, 0>(s, src, dst, a.H, a.W, a.r, a.n);
     if (rc != ASW_OK) return rc;
-    if (a.r == 15 && !a.nan_safe && a.tune->q6_pair != 0) return launch_q6_pair(s, a, g, a.tune->band_q);
+    if (a.r == 15 && a.tune->q6_pair != 0) return launch_q6_pair(s, a, g, a.tune->band_q);
     QSrc<6> qs{a.ab, a.H, a.W, hstride};
     QDst<6, true> qd{g, a.q, a.H, a.W};
     // two columns per lane: 4.5 ms, one: 5.3 ms.  No load FIFO here (PF = 0): 16 floats per row and lane in flight twice over would
